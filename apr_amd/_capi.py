@@ -1,0 +1,89 @@
+"""ctypes binding of include/apr.h (libapr_amd.so).  Fails loudly if the library is missing:
+there is NO CPU fallback in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapr_amd.so")
+
+APR_OK = 0
+ERR_INVALID, ERR_DEVICE, ERR_MODEL, ERR_NOMEM, ERR_NOMODEL = -1, -2, -3, -4, -5
+FLAVOUR_GO, FLAVOUR_LIBROSA = 0, 1
+WARN_UNDERFLOW, WARN_OVERFLOW = 1, 2
+PROF_SLOTS = 16
+
+# every symbol include/apr.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "apr_device_count", "apr_version", "apr_engine_create", "apr_engine_destroy", "apr_engine_num_classes",
+    "apr_last_error", "apr_prepare", "apr_prepare_batch", "apr_infer", "apr_score", "apr_score_device",
+    "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable",
+    "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info",
+)
+
+
+class ProfileSlot(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("layer", C.c_int32), ("reserved", C.c_int32), ("ms", C.c_double),
+                ("launches", C.c_uint64), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+class AprError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"apr error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m apr_amd.build` (hipcc, gfx950). "
+            "apr_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u8p, f32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)
+    L.apr_device_count.restype = C.c_int
+    L.apr_version.restype = C.c_char_p
+    L.apr_engine_create.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.apr_engine_create.restype = C.c_int
+    L.apr_model_info.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.apr_model_info.restype = C.c_int
+    L.apr_engine_destroy.argtypes = [vp]
+    L.apr_engine_destroy.restype = None
+    L.apr_engine_num_classes.argtypes = [vp]
+    L.apr_engine_num_classes.restype = C.c_int
+    L.apr_last_error.argtypes = [vp]
+    L.apr_last_error.restype = C.c_char_p
+    L.apr_prepare.argtypes = [vp, C.c_int, u8p, C.c_size_t, f32p]
+    L.apr_prepare.restype = C.c_int
+    L.apr_prepare_batch.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
+    L.apr_prepare_batch.restype = C.c_int
+    L.apr_infer.argtypes = [vp, f32p, C.c_int, f32p]
+    L.apr_infer.restype = C.c_int
+    L.apr_score.argtypes = [vp, u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_int, f64p, vp, vp]
+    L.apr_score.restype = C.c_int
+    L.apr_score_device.argtypes = [vp, u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_int, f64p, vp, vp, f32p]
+    L.apr_score_device.restype = C.c_int
+    L.apr_prepare_batch_device.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
+    L.apr_prepare_batch_device.restype = C.c_int
+    L.apr_infer_device.argtypes = [vp, f32p, C.c_int, f32p]
+    L.apr_infer_device.restype = C.c_int
+    L.apr_sync.argtypes = [vp]
+    L.apr_sync.restype = C.c_int
+    L.apr_engine_stream.argtypes = [vp]
+    L.apr_engine_stream.restype = C.c_void_p
+    L.apr_profile_enable.argtypes = [vp, C.c_int]
+    L.apr_profile_enable.restype = C.c_int
+    L.apr_profile_reset.argtypes = [vp]
+    L.apr_profile_reset.restype = C.c_int
+    L.apr_profile_read.argtypes = [vp, C.POINTER(ProfileSlot), C.POINTER(C.c_int)]
+    L.apr_profile_read.restype = C.c_int
+    L.apr_synth_pcm.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_size_t, C.c_void_p]
+    L.apr_synth_pcm.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,646 @@
+// engine.hip -- C ABI (include/apr.h) of the MI355X-native DTrack detection engine.
+//
+// Host side of the hot path: table construction (Hann windows, twiddles, mel lenses of
+// both reference flavours), weight ingest and re-layout, buffer management, kernel
+// launches on one HIP stream per engine, HIP-event profiling.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/apr.h"
+#include "conv.hip.h"
+#include "frontend.hip.h"
+#include "model_parse.h"
+
+using namespace apr;
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct Layer {
+    int cin, cout, stride, hin, win, hout, wout;
+    float *d_w = nullptr;   // [9][cin][cout]
+    float *d_b = nullptr;   // [cout]
+    int bn_tile = 0;
+};
+
+struct ProfPair {
+    hipEvent_t a, b;
+    int slot;
+};
+
+}  // namespace
+
+struct apr_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_classes = 0;
+    int max_batch = 1024;
+    int features = 0, pool_pixels = 0;
+
+    // front end
+    std::vector<void *> allocs;   // everything hipMalloc'd (freed in destroy)
+    FrontendTables tab[2];
+    float *d_melT = nullptr;      // [max_batch][188][128]
+    float *d_spec = nullptr;      // [max_batch][128][188]
+
+    // CNN
+    std::vector<Layer> layers;
+    float *d_act[2] = {nullptr, nullptr};
+    float *d_wfc = nullptr, *d_bfc = nullptr;
+
+    // staging for the host-pointer entry points
+    uint8_t *d_pcm = nullptr;
+    size_t pcm_cap = 0;
+    double *d_probs = nullptr;
+    int32_t *d_label = nullptr;
+    uint8_t *d_match = nullptr;
+    float *d_logits = nullptr;
+
+    // profiling
+    bool prof_on = false;
+    apr_profile_slot slots[APR_PROF_SLOTS];
+    int n_slots = 0;
+    std::vector<ProfPair> pending;
+    std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t _r = (call);                                                                 \
+        if (_r != hipSuccess) {                                                                 \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_r);                       \
+            return APR_ERR_DEVICE;                                                              \
+        }                                                                                       \
+    } while (0)
+
+template <typename T>
+int dev_alloc(apr_engine *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t r = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+    if (r != hipSuccess) {
+        e->err = std::string("hipMalloc: ") + hipGetErrorString(r);
+        return APR_ERR_NOMEM;
+    }
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return APR_OK;
+}
+
+template <typename T>
+int dev_upload(apr_engine *e, T **p, const std::vector<T> &h)
+{
+    int rc = dev_alloc(e, p, h.size());
+    if (rc) return rc;
+    HIPCHK(e, hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return APR_OK;
+}
+
+// ---- mel lenses ------------------------------------------------------------------------------
+double hz_to_mel(double hz) { return 2595.0 * std::log10(1.0 + hz / 700.0); }        // dsp.go:158-160
+double mel_to_hz(double mel) { return 700.0 * (std::pow(10.0, mel / 2595.0) - 1.0); } // dsp.go:163-165
+
+struct Csr {
+    std::vector<int> start, len, off;
+    std::vector<float> w;
+};
+
+// src/model/dsp.go:31-80: FFT-bin-quantised, unnormalised HTK triangles.
+Csr mel_lens_go()
+{
+    const int nbins = kNfft / 2 + 1;
+    double pts[kNmels + 2];
+    const double mn = hz_to_mel(0.0), mx = hz_to_mel(APR_SAMPLE_RATE / 2.0);
+    const double step = (mx - mn) / (double)(kNmels + 1);
+    int bins[kNmels + 2];
+    for (int i = 0; i < kNmels + 2; i++) {
+        pts[i] = mel_to_hz(mn + (double)i * step);
+        bins[i] = (int)std::floor((kNfft + 1) * pts[i] / (double)APR_SAMPLE_RATE);
+    }
+    Csr c;
+    for (int m = 0; m < kNmels; m++) {
+        const int s = bins[m], ce = bins[m + 1], en = std::min(bins[m + 2], nbins);   // dsp.go:93-97 clamps end
+        c.start.push_back(s);
+        c.len.push_back(std::max(en - s, 0));
+        c.off.push_back((int)c.w.size());
+        for (int f = s; f < en; f++) {
+            double wv = 0.0;
+            if (f < ce) wv = (double)(f - s) / (double)(ce - s);
+            else wv = (double)(bins[m + 2] - f) / (double)(bins[m + 2] - ce);
+            c.w.push_back((float)wv);
+        }
+    }
+    return c;
+}
+
+// ai/model.py:28-34: librosa.filters.mel(htk=True, norm='slaney', dtype=float32).
+Csr mel_lens_librosa()
+{
+    const int nbins = kNfft / 2 + 1;
+    std::vector<double> ff(nbins), mf(kNmels + 2);
+    for (int k = 0; k < nbins; k++) ff[k] = (double)k * (APR_SAMPLE_RATE / 2.0) / (double)(nbins - 1);
+    const double mn = hz_to_mel(0.0), mx = hz_to_mel(APR_SAMPLE_RATE / 2.0);
+    for (int i = 0; i < kNmels + 2; i++) mf[i] = mel_to_hz(mn + (mx - mn) * (double)i / (double)(kNmels + 1));
+    Csr c;
+    for (int m = 0; m < kNmels; m++) {
+        const double fd0 = mf[m + 1] - mf[m], fd1 = mf[m + 2] - mf[m + 1], enorm = 2.0 / (mf[m + 2] - mf[m]);
+        int first = -1, last = -1;
+        std::vector<float> row(nbins);
+        for (int k = 0; k < nbins; k++) {
+            const double lo = -(mf[m] - ff[k]) / fd0, up = (mf[m + 2] - ff[k]) / fd1;
+            double wv = std::max(0.0, std::min(lo, up));
+            row[k] = (float)((double)(float)wv * enorm);
+            if (row[k] != 0.0f) { if (first < 0) first = k; last = k; }
+        }
+        if (first < 0) { first = 0; last = -1; }
+        c.start.push_back(first);
+        c.len.push_back(last - first + 1);
+        c.off.push_back((int)c.w.size());
+        for (int k = first; k <= last; k++) c.w.push_back(row[k]);
+    }
+    return c;
+}
+
+int build_frontend(apr_engine *e)
+{
+    std::vector<float2> tw(kNfft);
+    for (int i = 0; i < kNfft; i++) {
+        const double a = 2.0 * M_PI * (double)i / (double)kNfft;
+        tw[i] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+    }
+    float2 *d_tw = nullptr;
+    int rc = dev_upload(e, &d_tw, tw);
+    if (rc) return rc;
+    for (int fl = 0; fl < 2; fl++) {
+        std::vector<float> win(kNfft);
+        for (int n = 0; n < kNfft; n++) {
+            // go-dsp window.Hann (symmetric, model.go:123) vs librosa's periodic hann
+            const double den = fl == APR_FLAVOUR_GO ? (double)(kNfft - 1) : (double)kNfft;
+            win[n] = (float)(0.5 * (1.0 - std::cos(2.0 * M_PI * (double)n / den)));
+        }
+        Csr c = fl == APR_FLAVOUR_GO ? mel_lens_go() : mel_lens_librosa();
+        if ((int)c.w.size() > kMaxNnz) { e->err = "mel lens exceeds CSR capacity"; return APR_ERR_INVALID; }
+        float *d_win = nullptr, *d_w = nullptr;
+        int *d_s = nullptr, *d_l = nullptr, *d_o = nullptr;
+        if ((rc = dev_upload(e, &d_win, win)) || (rc = dev_upload(e, &d_w, c.w)) || (rc = dev_upload(e, &d_s, c.start)) ||
+            (rc = dev_upload(e, &d_l, c.len)) || (rc = dev_upload(e, &d_o, c.off)))
+            return rc;
+        FrontendTables &T = e->tab[fl];
+        T.window = d_win; T.tw = d_tw; T.mel_start = d_s; T.mel_len = d_l; T.mel_off = d_o; T.mel_w = d_w;
+        T.nnz = (int)c.w.size();
+        T.n_frames = fl == APR_FLAVOUR_GO ? (APR_SAMPLE_SIZE / 2 - kNfft) / kHop + 1 : 1 + (APR_SAMPLE_SIZE / 2) / kHop;
+        T.frame_origin = fl == APR_FLAVOUR_GO ? 0 : -(kNfft / 2);
+        T.librosa = fl;
+    }
+    if ((rc = dev_alloc(e, &e->d_melT, (size_t)e->max_batch * kSpecFrames * kNmels))) return rc;
+    if ((rc = dev_alloc(e, &e->d_spec, (size_t)e->max_batch * APR_SPEC_ELEMS))) return rc;
+    return APR_OK;
+}
+
+void add_slot(apr_engine *e, const char *name, int layer)
+{
+    apr_profile_slot &s = e->slots[e->n_slots++];
+    memset(&s, 0, sizeof s);
+    snprintf(s.name, sizeof s.name, "%s", name);
+    s.layer = layer;
+}
+
+int build_cnn(apr_engine *e, const ParsedModel &pm)
+{
+    if (pm.n_classes < 1 || pm.n_classes > APR_MAX_CLASSES) { e->err = "class count out of range"; return APR_ERR_MODEL; }
+    if ((int)pm.convs.size() + 3 > APR_PROF_SLOTS) { e->err = "too many conv layers"; return APR_ERR_MODEL; }
+    if (pm.features > 1024 || pm.features % 4) { e->err = "unsupported classifier width"; return APR_ERR_MODEL; }
+    int h = kNmels, w = kSpecFrames, rc;
+    size_t act_max = 0;
+    for (size_t l = 0; l < pm.convs.size(); l++) {
+        const ConvSpec &cv = pm.convs[l];
+        Layer L;
+        L.cin = cv.cin; L.cout = cv.cout; L.stride = cv.stride; L.hin = h; L.win = w;
+        L.hout = (h + 2 - 3) / cv.stride + 1;
+        L.wout = (w + 2 - 3) / cv.stride + 1;
+        if (l == 0) {
+            if (cv.cin != 1 || cv.cout != 32 || cv.stride != 1) { e->err = "first conv must be 1->32, stride 1"; return APR_ERR_MODEL; }
+        } else {
+            if (cv.cin % 32 || cv.cout % 64) { e->err = "conv widths must be multiples of 32 (in) / 64 (out)"; return APR_ERR_MODEL; }
+            L.bn_tile = cv.cout % 128 == 0 ? 128 : 64;
+        }
+        // re-layout [cout][cin][3][3] -> [tap][cin][cout]
+        std::vector<float> wt((size_t)9 * cv.cin * cv.cout);
+        for (int o = 0; o < cv.cout; o++)
+            for (int c = 0; c < cv.cin; c++)
+                for (int t = 0; t < 9; t++) wt[((size_t)t * cv.cin + c) * cv.cout + o] = cv.w[((size_t)o * cv.cin + c) * 9 + t];
+        if ((rc = dev_upload(e, &L.d_w, wt)) || (rc = dev_upload(e, &L.d_b, cv.b))) return rc;
+        act_max = std::max(act_max, (size_t)L.cout * L.hout * L.wout);
+        h = L.hout; w = L.wout;
+        e->layers.push_back(L);
+    }
+    e->n_classes = pm.n_classes;
+    e->features = pm.features;
+    e->pool_pixels = h * w;
+    if ((rc = dev_upload(e, &e->d_wfc, pm.fc_w)) || (rc = dev_upload(e, &e->d_bfc, pm.fc_b))) return rc;
+    for (int i = 0; i < 2; i++)
+        if ((rc = dev_alloc(e, &e->d_act[i], act_max * (size_t)e->max_batch))) return rc;
+    return APR_OK;
+}
+
+// ---- profiling --------------------------------------------------------------------------------
+hipEvent_t get_event(apr_engine *e)
+{
+    if (!e->free_events.empty()) { hipEvent_t ev = e->free_events.back(); e->free_events.pop_back(); return ev; }
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+    return ev;
+}
+
+struct ProfScope {
+    apr_engine *e;
+    hipEvent_t a = nullptr, b = nullptr;
+    int slot;
+    ProfScope(apr_engine *e_, int slot_, double flops, double bytes) : e(e_), slot(slot_)
+    {
+        if (!e->prof_on || slot < 0) return;
+        a = get_event(e); b = get_event(e);
+        if (!a || !b) { a = b = nullptr; return; }
+        hipEventRecord(a, e->stream);
+        e->slots[slot].flops += flops;
+        e->slots[slot].bytes += bytes;
+        e->slots[slot].launches += 1;
+    }
+    ~ProfScope()
+    {
+        if (!a) return;
+        hipEventRecord(b, e->stream);
+        e->pending.push_back({a, b, slot});
+    }
+};
+
+int prof_flush(apr_engine *e)
+{
+    if (e->pending.empty()) return APR_OK;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (auto &p : e->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) e->slots[p.slot].ms += (double)ms;
+        e->free_events.push_back(p.a);
+        e->free_events.push_back(p.b);
+    }
+    e->pending.clear();
+    return APR_OK;
+}
+
+// ---- launches ---------------------------------------------------------------------------------
+int run_frontend(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes, int n_windows, size_t stride,
+                 float *d_out)
+{
+    const FrontendTables &T = e->tab[flavour];
+    const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
+    {
+        ProfScope ps(e, 0, (double)n_windows * T.n_frames * 5.0 * kNfft * 11.0 + 2.0 * T.nnz * T.n_frames * n_windows,
+                     (double)n_windows * (std::min<size_t>(stride, APR_SAMPLE_SIZE) + (double)T.n_frames * kNmels * 4));
+        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride,
+                           n_windows, T, e->d_melT);
+    }
+    {
+        ProfScope ps(e, 1, 0.0, (double)n_windows * ((double)T.n_frames * kNmels * 4 + APR_SPEC_ELEMS * 4));
+        hipLaunchKernelGGL(db_norm_kernel, dim3(n_windows), dim3(256), 0, e->stream, e->d_melT, n_windows, T.n_frames,
+                           T.librosa, d_out);
+    }
+    HIPCHK(e, hipGetLastError());
+    return APR_OK;
+}
+
+template <int BM, int BN, int S>
+void launch_igemm(apr_engine *e, const Layer &L, const float *in, float *out, long long M)
+{
+    const int tiles_n = L.cout / BN;
+    const long long tiles_m = (M + BM - 1) / BM;   // M < 2^31: max_batch is capped at create
+    hipLaunchKernelGGL((conv3x3_igemm_f32<BM, BN, S>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, e->stream, in,
+                       L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n);
+}
+
+int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class, float *d_logits, double *d_probs,
+            int32_t *d_label, uint8_t *d_match)
+{
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    const float *in = d_spec;
+    for (size_t l = 0; l < e->layers.size(); l++) {
+        const Layer &L = e->layers[l];
+        float *out = e->d_act[l & 1];
+        const long long M = (long long)batch * L.hout * L.wout;
+        const double flops = 2.0 * (double)M * L.cout * 9.0 * L.cin;
+        const double bytes = 4.0 * ((double)batch * L.hin * L.win * L.cin + (double)M * L.cout + 9.0 * L.cin * L.cout);
+        ProfScope ps(e, 2 + (int)l, flops, bytes);
+        if (l == 0) {
+            const long long blocks = std::min<long long>((M + 31) / 32, 256 * 32);
+            hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, in, L.d_w, L.d_b, out, L.hin,
+                               L.win, M);
+        } else if (L.bn_tile == 128) {
+            if (L.stride == 1) launch_igemm<128, 128, 1>(e, L, in, out, M);
+            else launch_igemm<128, 128, 2>(e, L, in, out, M);
+        } else {
+            if (L.stride == 1) launch_igemm<128, 64, 1>(e, L, in, out, M);
+            else launch_igemm<128, 64, 2>(e, L, in, out, M);
+        }
+        in = out;
+    }
+    {
+        ProfScope ps(e, 2 + (int)e->layers.size(), 2.0 * batch * e->features * e->n_classes,
+                     4.0 * batch * e->pool_pixels * e->features);
+        hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), 0, e->stream, in, e->pool_pixels, e->features, e->d_wfc,
+                           e->d_bfc, e->n_classes, trust, empty_class, d_logits, d_probs, d_label, d_match);
+    }
+    HIPCHK(e, hipGetLastError());
+    return APR_OK;
+}
+
+int ensure_staging(apr_engine *e, size_t pcm_bytes)
+{
+    int rc;
+    if (pcm_bytes > e->pcm_cap) {
+        size_t cap = std::max(pcm_bytes, (size_t)e->max_batch * APR_BYTES_PER_SECOND + APR_SAMPLE_SIZE);
+        if ((rc = dev_alloc(e, &e->d_pcm, cap + 16))) return rc;   // old buffer stays in allocs until destroy
+        e->pcm_cap = cap;
+    }
+    if (!e->d_probs) {
+        const size_t c = std::max(e->n_classes, 1);
+        if ((rc = dev_alloc(e, &e->d_probs, (size_t)e->max_batch * c)) || (rc = dev_alloc(e, &e->d_logits, (size_t)e->max_batch * c)) ||
+            (rc = dev_alloc(e, &e->d_label, (size_t)e->max_batch)) || (rc = dev_alloc(e, &e->d_match, (size_t)e->max_batch)))
+            return rc;
+    }
+    return APR_OK;
+}
+
+// bytes of `pcm` that windows [w0, w0+nw) touch, relative to window w0's start
+size_t span_bytes(size_t total_bytes, size_t w0, size_t nw, size_t stride)
+{
+    const size_t off = w0 * stride;
+    if (off >= total_bytes || nw == 0) return 0;
+    const size_t want = (nw - 1) * stride + APR_SAMPLE_SIZE;
+    return std::min(want, total_bytes - off);
+}
+
+int check_engine(apr_engine *e)
+{
+    if (!e) return APR_ERR_INVALID;
+    if (hipSetDevice(e->device) != hipSuccess) { e->err = "hipSetDevice failed"; return APR_ERR_DEVICE; }
+    return APR_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int apr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *apr_version(void) { return "apr_amd 0.1 (gfx950)"; }
+
+int apr_model_info(const void *model_bytes, size_t n, int *n_classes, int *n_conv_layers)
+{
+    ParsedModel pm;
+    std::string perr;
+    if (!model_bytes || !n) { g_create_err = "model: empty"; return APR_ERR_MODEL; }
+    if (!parse_model(model_bytes, n, pm, perr)) { g_create_err = "model: " + perr; return APR_ERR_MODEL; }
+    if (n_classes) *n_classes = pm.n_classes;
+    if (n_conv_layers) *n_conv_layers = (int)pm.convs.size();
+    return APR_OK;
+}
+
+int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out)
+{
+    if (!out) return APR_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_err = "no HIP device available"; return APR_ERR_DEVICE; }
+    if (device_id < 0 || device_id >= ndev) { g_create_err = "device_id out of range"; return APR_ERR_INVALID; }
+    ParsedModel pm;
+    const bool has_model = model_bytes && n;
+    if (has_model) {
+        std::string perr;
+        if (!parse_model(model_bytes, n, pm, perr)) { g_create_err = "model: " + perr; return APR_ERR_MODEL; }
+    }
+    apr_engine *e = new (std::nothrow) apr_engine();
+    if (!e) { g_create_err = "out of host memory"; return APR_ERR_NOMEM; }
+    e->device = device_id;
+    e->max_batch = max_batch > 0 ? std::min(max_batch, 16384) : 1024;   // keeps every layer's pixel count < 2^31
+    add_slot(e, "stft_mel_kernel", -1);
+    add_slot(e, "db_norm_kernel", -1);
+    int rc = APR_OK;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        e->err = "could not create a stream on the device";
+        rc = APR_ERR_DEVICE;
+    }
+    if (!rc) rc = build_frontend(e);
+    if (!rc && has_model) rc = build_cnn(e, pm);
+    if (!rc && has_model) {
+        for (size_t l = 0; l < e->layers.size(); l++) {
+            const Layer &L = e->layers[l];
+            char nm[48];
+            if (l == 0) snprintf(nm, sizeof nm, "conv1_kernel");
+            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<128, %d, %d>", L.bn_tile, L.stride);
+            add_slot(e, nm, (int)l + 1);
+        }
+        add_slot(e, "head_kernel", -1);
+    }
+    if (rc) {
+        g_create_err = e->err;
+        apr_engine_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return APR_OK;
+}
+
+void apr_engine_destroy(apr_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto ev : e->free_events) hipEventDestroy(ev);
+    for (void *p : e->allocs) hipFree(p);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int apr_engine_num_classes(const apr_engine *e) { return e ? e->n_classes : 0; }
+
+const char *apr_last_error(const apr_engine *e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+void *apr_engine_stream(apr_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+int apr_sync(apr_engine *e)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return APR_OK;
+}
+
+int apr_prepare_batch_device(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes, size_t n_windows,
+                             size_t stride_bytes, float *d_out)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if ((flavour != APR_FLAVOUR_GO && flavour != APR_FLAVOUR_LIBROSA) || (n_windows && (!d_pcm || !d_out)) || (n_windows > 1 && !stride_bytes)) {
+        e->err = "apr_prepare_batch_device: bad argument";
+        return APR_ERR_INVALID;
+    }
+    for (size_t w0 = 0; w0 < n_windows; w0 += (size_t)e->max_batch) {
+        const size_t nw = std::min<size_t>(e->max_batch, n_windows - w0);
+        const size_t off = w0 * stride_bytes;
+        const size_t rem = off < total_bytes ? total_bytes - off : 0;
+        if ((rc = run_frontend(e, flavour, d_pcm + std::min(off, total_bytes), rem, (int)nw, stride_bytes, d_out + w0 * APR_SPEC_ELEMS))) return rc;
+    }
+    return APR_OK;
+}
+
+int apr_prepare_batch(apr_engine *e, int flavour, const uint8_t *pcm, size_t total_bytes, size_t n_windows, size_t stride_bytes,
+                      float *out)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if ((flavour != APR_FLAVOUR_GO && flavour != APR_FLAVOUR_LIBROSA) || (n_windows && !out) || (total_bytes && !pcm) || (n_windows > 1 && !stride_bytes)) {
+        e->err = "apr_prepare_batch: bad argument";
+        return APR_ERR_INVALID;
+    }
+    int warn = 0;
+    for (size_t w0 = 0; w0 < n_windows; w0 += (size_t)e->max_batch) {
+        const size_t nw = std::min<size_t>(e->max_batch, n_windows - w0);
+        const size_t span = span_bytes(total_bytes, w0, nw, stride_bytes);
+        if (span < (nw - 1) * stride_bytes + APR_SAMPLE_SIZE) warn |= APR_WARN_UNDERFLOW;
+        if ((rc = ensure_staging(e, span))) return rc;
+        if (span) HIPCHK(e, hipMemcpyAsync(e->d_pcm, pcm + w0 * stride_bytes, span, hipMemcpyHostToDevice, e->stream));
+        if ((rc = run_frontend(e, flavour, e->d_pcm, span, (int)nw, stride_bytes, e->d_spec))) return rc;
+        HIPCHK(e, hipMemcpyAsync(out + w0 * APR_SPEC_ELEMS, e->d_spec, nw * APR_SPEC_ELEMS * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return warn;
+}
+
+int apr_prepare(apr_engine *e, int flavour, const uint8_t *pcm, size_t nbytes, float *out)
+{
+    if (!e) return APR_ERR_INVALID;
+    int warn = 0;
+    if (nbytes > APR_SAMPLE_SIZE) { warn |= APR_WARN_OVERFLOW; nbytes = APR_SAMPLE_SIZE; }   // model.go:93-96
+    int rc = apr_prepare_batch(e, flavour, pcm, nbytes, 1, APR_SAMPLE_SIZE, out);
+    return rc < 0 ? rc : (rc | warn);
+}
+
+int apr_infer_device(apr_engine *e, const float *d_spec, int batch, float *d_logits)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (batch < 0 || (batch && (!d_spec || !d_logits))) { e->err = "apr_infer_device: bad argument"; return APR_ERR_INVALID; }
+    for (int b0 = 0; b0 < batch; b0 += e->max_batch) {
+        const int nb = std::min(e->max_batch, batch - b0);
+        if ((rc = run_cnn(e, d_spec + (size_t)b0 * APR_SPEC_ELEMS, nb, 0.0, -1, d_logits + (size_t)b0 * e->n_classes, nullptr, nullptr, nullptr))) return rc;
+    }
+    return APR_OK;
+}
+
+int apr_infer(apr_engine *e, const float *spec, int batch, float *out_logits)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if (batch < 0 || (batch && (!spec || !out_logits))) { e->err = "apr_infer: bad argument"; return APR_ERR_INVALID; }
+    if ((rc = ensure_staging(e, 0))) return rc;
+    for (int b0 = 0; b0 < batch; b0 += e->max_batch) {
+        const int nb = std::min(e->max_batch, batch - b0);
+        HIPCHK(e, hipMemcpyAsync(e->d_spec, spec + (size_t)b0 * APR_SPEC_ELEMS, (size_t)nb * APR_SPEC_ELEMS * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        if ((rc = run_cnn(e, e->d_spec, nb, 0.0, -1, e->d_logits, nullptr, nullptr, nullptr))) return rc;
+        HIPCHK(e, hipMemcpyAsync(out_logits + (size_t)b0 * e->n_classes, e->d_logits, (size_t)nb * e->n_classes * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return APR_OK;
+}
+
+int apr_score_device(apr_engine *e, const uint8_t *d_pcm, size_t total_bytes, size_t n_windows, size_t stride_bytes, double trust,
+                     int empty_class, double *d_probs, int32_t *d_label, uint8_t *d_match, float *d_logits)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if ((n_windows && !d_pcm) || (n_windows > 1 && !stride_bytes)) { e->err = "apr_score_device: bad argument"; return APR_ERR_INVALID; }
+    const int C = e->n_classes;
+    for (size_t w0 = 0; w0 < n_windows; w0 += (size_t)e->max_batch) {
+        const size_t nw = std::min<size_t>(e->max_batch, n_windows - w0);
+        const size_t off = w0 * stride_bytes;
+        const size_t rem = off < total_bytes ? total_bytes - off : 0;
+        if ((rc = run_frontend(e, APR_FLAVOUR_GO, d_pcm + std::min(off, total_bytes), rem, (int)nw, stride_bytes, e->d_spec))) return rc;
+        if ((rc = run_cnn(e, e->d_spec, (int)nw, trust, empty_class, d_logits ? d_logits + w0 * C : nullptr,
+                          d_probs ? d_probs + w0 * C : nullptr, d_label ? d_label + w0 : nullptr, d_match ? d_match + w0 : nullptr)))
+            return rc;
+    }
+    return APR_OK;
+}
+
+int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_windows, size_t stride_bytes, double trust,
+              int empty_class, double *probs, int32_t *label, uint8_t *match)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if ((total_bytes && !pcm) || (n_windows > 1 && !stride_bytes)) { e->err = "apr_score: bad argument"; return APR_ERR_INVALID; }
+    const int C = e->n_classes;
+    for (size_t w0 = 0; w0 < n_windows; w0 += (size_t)e->max_batch) {
+        const size_t nw = std::min<size_t>(e->max_batch, n_windows - w0);
+        const size_t span = span_bytes(total_bytes, w0, nw, stride_bytes);
+        if ((rc = ensure_staging(e, span))) return rc;
+        if (span) HIPCHK(e, hipMemcpyAsync(e->d_pcm, pcm + w0 * stride_bytes, span, hipMemcpyHostToDevice, e->stream));
+        if ((rc = run_frontend(e, APR_FLAVOUR_GO, e->d_pcm, span, (int)nw, stride_bytes, e->d_spec))) return rc;
+        if ((rc = run_cnn(e, e->d_spec, (int)nw, trust, empty_class, nullptr, e->d_probs, e->d_label, e->d_match))) return rc;
+        if (probs) HIPCHK(e, hipMemcpyAsync(probs + w0 * C, e->d_probs, nw * C * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (label) HIPCHK(e, hipMemcpyAsync(label + w0, e->d_label, nw * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        if (match) HIPCHK(e, hipMemcpyAsync(match + w0, e->d_match, nw, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return APR_OK;
+}
+
+int apr_profile_enable(apr_engine *e, int on)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (!on) rc = prof_flush(e);
+    e->prof_on = on != 0;
+    return rc;
+}
+
+int apr_profile_reset(apr_engine *e)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if ((rc = prof_flush(e))) return rc;
+    for (int i = 0; i < e->n_slots; i++) { e->slots[i].ms = 0; e->slots[i].launches = 0; e->slots[i].flops = 0; e->slots[i].bytes = 0; }
+    return APR_OK;
+}
+
+int apr_profile_read(apr_engine *e, apr_profile_slot *slots, int *n_slots)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (!slots || !n_slots) return APR_ERR_INVALID;
+    if ((rc = prof_flush(e))) return rc;
+    memcpy(slots, e->slots, sizeof(apr_profile_slot) * e->n_slots);
+    *n_slots = e->n_slots;
+    return APR_OK;
+}
+
+}  // extern "C"

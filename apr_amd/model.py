@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's Go package ``dtrack/model`` over the C ABI.
+
+Same names, argument meaning and error behaviour as ``src/model/model.go``:
+constants (model.go:23-40), ``OnnxModel`` (model.go:43-46), ``Train`` (model.go:49-51),
+``Load`` (model.go:54-83), ``Prepare`` (model.go:86-184), ``Infer`` (model.go:188-229),
+plus the batch entry points the sweep uses (``Engine.score`` ...).  The Go toolchain is
+absent in the build image, so this Python module is what the parity tests drive; the
+cgo shim a maintainer would add is shown in INTEGRATION.md and go/model/model.go.
+
+All arithmetic runs in libapr_amd.so on the GPU.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+import os
+import sys
+import weakref
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import AprError, FLAVOUR_GO, FLAVOUR_LIBROSA, WARN_OVERFLOW, WARN_UNDERFLOW
+
+# ---- src/ffmpeg/ffmpeg.go:20-21 ----
+SampleRate = 48000
+BytesPerSecond = 96000
+# ---- src/model/model.go:23-40 ----
+SegmentSize = 2
+SampleSize = BytesPerSecond * SegmentSize
+Nmels = 128
+Nfft = 2048
+HopLength = 512
+SpectrogramFrames = 188
+Int16Max = 32768.0
+MaxFreq = float(SampleRate) / 2
+MinFreq = 0.0
+
+
+class Die(SystemExit):
+    """log.Die (src/log/log.go:42-46): '[ERROR]\\t msg' on stderr, exit status 1."""
+
+    def __init__(self, msg: str):
+        sys.stderr.write(f"[ERROR]\t {msg}\n")
+        super().__init__(1)
+
+
+def _warn(msg: str) -> None:  # log.Warn (src/log/log.go:36-39)
+    sys.stderr.write(f"[WARN]\t {msg}\n")
+
+
+@dataclass
+class OnnxModel:
+    """model.go:43-46"""
+    RawBytes: bytes = b""
+    Labels: List[str] = field(default_factory=list)
+
+
+def Train() -> None:  # model.go:49-51
+    print("[INFO]\t Model Training is handled by python -m ai.train")
+
+
+def Load(model_path: str) -> OnnxModel:
+    """model.go:54-83: read <name>.onnx and <name>.labels (JSON string array); Die on failure."""
+    try:
+        with open(model_path, "rb") as fh:
+            raw = fh.read()
+    except OSError as err:
+        raise Die(f"could not read ONNX file: {err}")
+    json_path = os.path.splitext(model_path)[0] + ".labels"
+    try:
+        with open(json_path, "rb") as fh:
+            labels_bytes = fh.read()
+    except OSError as err:
+        raise Die(f"could not read Labels file: {err}")
+    try:
+        labels = json.loads(labels_bytes)
+        if not isinstance(labels, list) or not all(isinstance(s, str) for s in labels):
+            raise ValueError("not a JSON array of strings")
+    except ValueError as err:
+        raise Die(f"could not parse Labels JSON: {err}")
+    return OnnxModel(RawBytes=raw, Labels=labels)
+
+
+# ------------------------------------------------------------------------------------------
+# Engine: one GPU stream + (optionally) one loaded model
+# ------------------------------------------------------------------------------------------
+def _addr(a) -> int:
+    """address of a numpy array (host) or a torch tensor (host or device)"""
+    if a is None:
+        return 0
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        if not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return a.data_ptr()
+    raise TypeError(type(a))
+
+
+def _as_u8(buf) -> np.ndarray:
+    if isinstance(buf, np.ndarray):
+        return np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    return np.frombuffer(buf, dtype=np.uint8)
+
+
+class Engine:
+    """apr_engine handle (include/apr.h).  ``model_bytes=None`` gives a front-end-only engine."""
+
+    def __init__(self, model_bytes: Optional[bytes] = None, device: int = 0, max_batch: int = 0):
+        self._lib = _capi.lib()
+        h = C.c_void_p()
+        mb = bytes(model_bytes) if model_bytes else None
+        rc = self._lib.apr_engine_create(mb, len(mb) if mb else 0, device, max_batch, C.byref(h))
+        if rc != 0:
+            raise AprError(rc, (self._lib.apr_last_error(None) or b"").decode())
+        self._h = h
+        self.device = device
+        self.num_classes = self._lib.apr_engine_num_classes(h)
+        self._fin = weakref.finalize(self, self._lib.apr_engine_destroy, h)
+
+    def close(self) -> None:
+        self._fin()
+
+    def _chk(self, rc: int) -> int:
+        if rc < 0:
+            raise AprError(rc, (self._lib.apr_last_error(self._h) or b"").decode())
+        return rc
+
+    # ---- host-pointer entry points ----
+    def prepare(self, pcm, flavour: int = FLAVOUR_GO):
+        b = _as_u8(pcm)
+        out = np.empty((Nmels, SpectrogramFrames), np.float32)
+        warn = self._chk(self._lib.apr_prepare(self._h, flavour, b.ctypes.data, b.size, out.ctypes.data))
+        return out, warn
+
+    def prepare_batch(self, pcm, n_windows: int, stride: int = BytesPerSecond, flavour: int = FLAVOUR_GO):
+        b = _as_u8(pcm)
+        out = np.empty((n_windows, Nmels, SpectrogramFrames), np.float32)
+        self._chk(self._lib.apr_prepare_batch(self._h, flavour, b.ctypes.data, b.size, n_windows, stride, out.ctypes.data))
+        return out
+
+    def infer_logits(self, spec) -> np.ndarray:
+        s = np.ascontiguousarray(spec, np.float32).reshape(-1, Nmels, SpectrogramFrames)
+        out = np.empty((s.shape[0], self.num_classes), np.float32)
+        self._chk(self._lib.apr_infer(self._h, s.ctypes.data, s.shape[0], out.ctypes.data))
+        return out
+
+    def score(self, pcm, n_windows: Optional[int] = None, stride: int = BytesPerSecond, trust: float = 0.5,
+              empty_class: int = -1):
+        """Fused sweep over one PCM buffer -> dict(probs [n,C] f64, label [n] i32, match [n] u8)."""
+        b = _as_u8(pcm)
+        if n_windows is None:
+            n_windows = windows_in(b.size, stride)
+        probs = np.empty((n_windows, self.num_classes), np.float64)
+        label = np.empty(n_windows, np.int32)
+        match = np.empty(n_windows, np.uint8)
+        self._chk(self._lib.apr_score(self._h, b.ctypes.data, b.size, n_windows, stride, trust, empty_class,
+                                      probs.ctypes.data, label.ctypes.data, match.ctypes.data))
+        return dict(probs=probs, label=label, match=match)
+
+    # ---- device-resident entry points (torch tensors on this engine's GPU) ----
+    def score_device(self, d_pcm, total_bytes: int, n_windows: int, stride: int, trust: float, empty_class: int,
+                     d_probs=None, d_label=None, d_match=None, d_logits=None) -> None:
+        self._chk(self._lib.apr_score_device(self._h, _addr(d_pcm), total_bytes, n_windows, stride, trust, empty_class,
+                                             _addr(d_probs), _addr(d_label), _addr(d_match), _addr(d_logits)))
+
+    def prepare_batch_device(self, d_pcm, total_bytes: int, n_windows: int, stride: int, d_out,
+                             flavour: int = FLAVOUR_GO) -> None:
+        self._chk(self._lib.apr_prepare_batch_device(self._h, flavour, _addr(d_pcm), total_bytes, n_windows, stride,
+                                                     _addr(d_out)))
+
+    def infer_device(self, d_spec, batch: int, d_logits) -> None:
+        self._chk(self._lib.apr_infer_device(self._h, _addr(d_spec), batch, _addr(d_logits)))
+
+    def sync(self) -> None:
+        self._chk(self._lib.apr_sync(self._h))
+
+    # ---- profiling ----
+    def profile_enable(self, on: bool = True) -> None:
+        self._chk(self._lib.apr_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self) -> None:
+        self._chk(self._lib.apr_profile_reset(self._h))
+
+    def profile_read(self):
+        slots = (_capi.ProfileSlot * _capi.PROF_SLOTS)()
+        n = C.c_int(0)
+        self._chk(self._lib.apr_profile_read(self._h, slots, C.byref(n)))
+        return [dict(name=s.name.decode(), layer=s.layer, ms=s.ms, launches=s.launches, flops=s.flops, bytes=s.bytes)
+                for s in slots[: n.value]]
+
+
+def windows_in(n_bytes: int, stride: int = BytesPerSecond) -> int:
+    """2-s windows with 1-s hop in a recording: ai/inspect.py:108-109 ``range(0, len-bps, bps)``
+    (= T-1 for T whole seconds; daemon.go:115-125 delays by one segment the same way)."""
+    if n_bytes <= stride:
+        return 0
+    return len(range(0, n_bytes - stride, stride))
+
+
+# ------------------------------------------------------------------------------------------
+# The reference's package-level functions
+# ------------------------------------------------------------------------------------------
+_frontend: Dict[int, Engine] = {}
+_engines: Dict[tuple, Engine] = {}
+_default_device = 0
+
+
+def set_device(device: int) -> None:
+    global _default_device
+    _default_device = device
+
+
+def _frontend_engine() -> Engine:
+    e = _frontend.get(_default_device)
+    if e is None:
+        e = _frontend[_default_device] = Engine(None, _default_device, 64)
+    return e
+
+
+def Prepare(pcmData: bytes) -> np.ndarray:
+    """model.go:86-184.  Returns the float32 tensor of shape [1,1,128,188]; warns like the
+    reference on short / long input.  (The reference's error return is always nil.)"""
+    out, warn = _frontend_engine().prepare(pcmData, FLAVOUR_GO)
+    if warn & WARN_UNDERFLOW:
+        _warn("Audio Underflow; Segment was not large enough!")
+    if warn & WARN_OVERFLOW:
+        _warn("Audio Overflow; Segment was too large!")
+    return out.reshape(1, 1, Nmels, SpectrogramFrames)
+
+
+def engine_for(inferModel: OnnxModel, max_batch: int = 0) -> Engine:
+    """Device-resident engine cached by the identity of RawBytes: removes the per-call
+    backend build + UnmarshalBinary of model.go:190-196 without changing the API."""
+    key = (id(inferModel.RawBytes), len(inferModel.RawBytes), _default_device)
+    e = _engines.get(key)
+    if e is None:
+        try:
+            e = Engine(inferModel.RawBytes, _default_device, max_batch)
+        except AprError as err:
+            raise Die(f"could not unmarshal ONNX model: {err}")
+        _engines[key] = e
+    return e
+
+
+def softmax(logits) -> List[float]:
+    """model.go:232-254, float64."""
+    mx = -sys.float_info.max
+    for v in logits:
+        if v > mx:
+            mx = v
+    exps = [math.exp(v - mx) for v in logits]
+    s = 0.0
+    for v in exps:
+        s += v
+    return [v / s for v in exps]
+
+
+def Infer(inferModel: OnnxModel, preparedAudio: np.ndarray) -> Dict[str, float]:
+    """model.go:188-229: logits on the GPU, f64 softmax and label map on the host."""
+    e = engine_for(inferModel, 64)
+    try:
+        logits = e.infer_logits(np.asarray(preparedAudio, np.float32).reshape(1, Nmels, SpectrogramFrames))[0]
+    except AprError as err:
+        raise Die(f"Inference failed: {err}")
+    probs = softmax([float(v) for v in logits])           # model.go:212-218
+    results: Dict[str, float] = {}
+    for i, label in enumerate(inferModel.Labels):          # model.go:221-226
+        if i < len(probs):
+            results[label] = probs[i]
+    return results
+
+
+def decide(predictions: Dict[str, float], trust: float):
+    """src/daemon/daemon.go:189-207 -> (bestClass, bestConf, match)."""
+    best, conf = "", 0.0
+    for label, score in predictions.items():
+        if score > conf:
+            conf, best = score, label
+    return best, conf, (best != "empty" and conf > trust)
+
+
+def audio_to_spectrogram(pcm: bytes) -> np.ndarray:
+    """ai/model.py:184-204 on normalize_audio(pcm) for one .dat clip -> [1,128,188] f32."""
+    out, _ = _frontend_engine().prepare(pcm, FLAVOUR_LIBROSA)
+    return out.reshape(1, Nmels, SpectrogramFrames)
+
+
+def synth_pcm(base_seed: int, file_index: int, n_seconds: int, second_offset: int = 0) -> np.ndarray:
+    """Deterministic synthetic 48 kHz s16 recording (apr_synth_pcm, host side)."""
+    out = np.empty(n_seconds * SampleRate, np.int16)
+    rc = _capi.lib().apr_synth_pcm(base_seed, file_index, second_offset, n_seconds, out.ctypes.data)
+    if rc:
+        raise AprError(rc, "apr_synth_pcm")
+    return out
+
+
+def model_info(model_bytes: bytes):
+    """apr_model_info: (n_classes, n_conv_layers) or AprError with the parser's message.  No GPU."""
+    L = _capi.lib()
+    nc, nl = C.c_int(0), C.c_int(0)
+    rc = L.apr_model_info(bytes(model_bytes), len(model_bytes), C.byref(nc), C.byref(nl))
+    if rc:
+        raise AprError(rc, (L.apr_last_error(None) or b"").decode())
+    return nc.value, nl.value

@@ -1,0 +1,192 @@
+/*
+ * apr.h -- C ABI of the MI355X-native DTrack detection engine (libapr_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of audio-pattern-ranger/apr:
+ *   PCM (48 kHz mono s16le, 2-s windows, 1-s hop) -> STFT -> log-mel -> NoiseDetector
+ *   CNN -> softmax -> threshold/label.
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * the reference repository).  Conventions: extern "C", plain pointers and sizes,
+ * return 0 (APR_OK) or a negative error code (the prepare calls return a
+ * non-negative warn-flag mask), no exceptions cross this boundary, every output
+ * buffer is caller-allocated, nothing passed in is retained after the call
+ * returns.  One engine handle owns one GPU stream and is safe for ONE caller at
+ * a time (the daemon pattern, src/daemon/daemon.go:93-99, is one handle per
+ * model goroutine plus one front-end-only handle for Prepare).
+ */
+#ifndef APR_H
+#define APR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- constants: src/ffmpeg/ffmpeg.go:20-21, src/model/model.go:23-40 ---- */
+#define APR_SAMPLE_RATE        48000
+#define APR_BYTES_PER_SECOND   96000
+#define APR_SEGMENT_SIZE       2
+#define APR_SAMPLE_SIZE        192000   /* bytes in one 2-s check window        */
+#define APR_NMELS              128
+#define APR_NFFT               2048
+#define APR_HOP_LENGTH         512
+#define APR_SPECTROGRAM_FRAMES 188
+#define APR_SPEC_ELEMS         (APR_NMELS * APR_SPECTROGRAM_FRAMES)
+#define APR_MAX_CLASSES        64
+
+/* error codes */
+#define APR_OK            0
+#define APR_ERR_INVALID  -1   /* bad argument                                   */
+#define APR_ERR_DEVICE   -2   /* HIP runtime error / no such device             */
+#define APR_ERR_MODEL    -3   /* model bytes are not a NoiseDetector graph      */
+#define APR_ERR_NOMEM    -4
+#define APR_ERR_NOMODEL  -5   /* CNN entry point called on a front-end-only engine */
+
+/* front-end flavour: the reference has two, numerically different */
+#define APR_FLAVOUR_GO      0 /* src/model/model.go:86-184 + src/model/dsp.go   */
+#define APR_FLAVOUR_LIBROSA 1 /* ai/model.py:184-204 (training / ai.inspect)    */
+
+/* warn flags returned by the prepare calls (log.Warn sites model.go:89,94)     */
+#define APR_WARN_UNDERFLOW 1  /* "Audio Underflow; Segment was not large enough!" */
+#define APR_WARN_OVERFLOW  2  /* "Audio Overflow; Segment was too large!"        */
+
+typedef struct apr_engine apr_engine;
+
+/* Number of HIP devices visible (0 if none / runtime unusable). */
+int apr_device_count(void);
+
+/* Library version string. */
+const char *apr_version(void);
+
+/*
+ * Create an engine on GPU `device_id`.
+ *   model_bytes/n : the bytes model.Load keeps in OnnxModel.RawBytes
+ *                   (src/model/model.go:54-83): an ONNX file as exported by
+ *                   ai/model.py:143-152 (Conv[+BatchNormalization]+Relu x12,
+ *                   GlobalMaxPool, Flatten, Gemm), or this repo's flat "APRW"
+ *                   blob (apr_amd/weights.py).  NULL/0 creates a
+ *                   front-end-only engine (enough for Prepare).
+ *   max_batch     : windows processed per GPU pass (activation buffers are
+ *                   sized for it); <=0 picks the default (1024).
+ * Replaces the per-call `gorgonnx.NewGraph()` + `UnmarshalBinary` of
+ * src/model/model.go:190-196: parsing and upload happen once, here.
+ */
+int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out);
+void apr_engine_destroy(apr_engine *e);
+
+/*
+ * Host-only validation of model bytes (no GPU touched): parses exactly as
+ * apr_engine_create would and reports the class count and conv-layer count.
+ * On failure returns APR_ERR_MODEL and apr_last_error(NULL) says why -- the
+ * text the Go shim passes to log.Die("could not unmarshal ONNX model: %s")
+ * (src/model/model.go:194-196).
+ */
+int apr_model_info(const void *model_bytes, size_t n, int *n_classes, int *n_conv_layers);
+
+/* Number of classes C of the loaded model (0 for a front-end-only engine). */
+int apr_engine_num_classes(const apr_engine *e);
+
+/* Last error text of this engine (or of the last failed create when e == NULL). */
+const char *apr_last_error(const apr_engine *e);
+
+/*
+ * model.Prepare (src/model/model.go:86): s16le bytes -> [128][188] float32
+ * spectrogram (row-major, the backing array of the reference's [1,1,128,188]
+ * tensor).  Pad/truncate semantics of model.go:87-96.  Host pointers.
+ * Returns a warn-flag mask >= 0, or a negative error.
+ * flavour APR_FLAVOUR_LIBROSA replaces ai.model.audio_to_spectrogram
+ * (ai/model.py:184) on normalize_audio(pcm) for a 192000-byte clip.
+ */
+int apr_prepare(apr_engine *e, int flavour, const uint8_t *pcm_s16le, size_t nbytes, float *out_128x188);
+
+/*
+ * Batched Prepare: window k = bytes [k*stride, k*stride + 192000) of `pcm`
+ * clipped to total_bytes (short tail windows are zero-padded like model.go:88-92).
+ * stride 96000 reproduces the daemon's / ai.inspect's 2-s window with 1-s hop
+ * (src/daemon/daemon.go:104-125, ai/inspect.py:106-109); stride 192000 walks a
+ * packed array of .dat clips (ai/train.py:36-52, BASELINE config 5).
+ * out: [n_windows][128][188] float32, host.
+ */
+int apr_prepare_batch(apr_engine *e, int flavour, const uint8_t *pcm, size_t total_bytes, size_t n_windows,
+                      size_t stride_bytes, float *out);
+
+/*
+ * The CNN half of model.Infer (src/model/model.go:188-209): `batch` prepared
+ * spectrograms [batch][128][188] -> raw logits [batch][C] float32 (what
+ * outputTensors[0] holds).  Host pointers.  The f64 softmax + label map of
+ * model.go:211-228 stays on the caller's side (Go shim / apr_amd.model.Infer),
+ * exactly as in the reference.
+ */
+int apr_infer(apr_engine *e, const float *spec, int batch, float *out_logits);
+
+/*
+ * Fused batch path: Prepare (go flavour) + Infer + softmax + the daemon's
+ * decision rule (src/daemon/daemon.go:189-207) for n_windows windows of one PCM
+ * buffer (window k as in apr_prepare_batch).
+ *   trust       : inspect_trust (src/state/config.go:86), match needs conf > trust
+ *   empty_class : index of the "empty" label, or -1 if the model has none
+ *   probs       : [n_windows][C] float64  (the values of Infer's map)
+ *   label       : [n_windows] argmax class index (-1 if no prob > 0)
+ *   match       : [n_windows] 1 iff label != empty_class && conf > trust
+ * Any of probs/label/match may be NULL.  Host pointers.
+ */
+int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_windows, size_t stride_bytes,
+              double trust, int empty_class, double *probs, int32_t *label, uint8_t *match);
+
+/*
+ * Same as apr_score with every buffer already resident in this engine's GPU
+ * memory (hipMalloc'd / torch device tensors).  Asynchronous on the engine's
+ * stream; call apr_sync before reading the outputs.  d_logits (optional)
+ * receives the raw f32 logits.  This is what bench.py times.
+ */
+int apr_score_device(apr_engine *e, const uint8_t *d_pcm, size_t total_bytes, size_t n_windows,
+                     size_t stride_bytes, double trust, int empty_class, double *d_probs, int32_t *d_label,
+                     uint8_t *d_match, float *d_logits);
+
+/* Device-resident batched Prepare (BASELINE config 5).  Asynchronous. */
+int apr_prepare_batch_device(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes,
+                             size_t n_windows, size_t stride_bytes, float *d_out);
+
+/* Device-resident CNN: d_spec [batch][128][188] -> d_logits [batch][C].  Asynchronous. */
+int apr_infer_device(apr_engine *e, const float *d_spec, int batch, float *d_logits);
+
+/* Block until all work queued on this engine's stream has finished. */
+int apr_sync(apr_engine *e);
+
+/* The hipStream_t this engine launches on (as void*), for event timing by the caller. */
+void *apr_engine_stream(apr_engine *e);
+
+/*
+ * Per-kernel timing with HIP events on the engine's stream (no reference
+ * counterpart; measurement hook for bench.py).  While enabled, every kernel
+ * launch is bracketed by events; apr_profile_read syncs and accumulates.
+ */
+#define APR_PROF_SLOTS 16
+typedef struct apr_profile_slot {
+    char     name[48];     /* kernel (family) name as rocprofv3 reports it     */
+    int32_t  layer;        /* 1..12 for conv layers, -1 otherwise               */
+    int32_t  reserved;
+    double   ms;           /* summed device time                                */
+    uint64_t launches;
+    double   flops;        /* algorithmic FLOPs issued by those launches        */
+    double   bytes;        /* algorithmic HBM bytes of those launches           */
+} apr_profile_slot;
+int apr_profile_enable(apr_engine *e, int on);
+int apr_profile_reset(apr_engine *e);
+int apr_profile_read(apr_engine *e, apr_profile_slot *slots /*[APR_PROF_SLOTS]*/, int *n_slots);
+
+/*
+ * Deterministic synthetic PCM (host side, no GPU): SURVEY 8(d) recipe.  A 16 kHz
+ * signal (noise at -30 dBFS, 0-3 Hann-shaped tone/chirp bursts per second,
+ * exact-zero stretches) interpolated x3 to 48 kHz, s16 saturated.  file seed =
+ * mix(base_seed, file_index); any sample range of a file can be generated
+ * independently (sample_offset is in 48 kHz samples, multiple of 48000).
+ */
+int apr_synth_pcm(uint64_t base_seed, uint64_t file_index, uint64_t second_offset, size_t n_seconds,
+                  int16_t *out_48k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APR_H */

@@ -1,0 +1,177 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
+committed golden vectors.  Tolerances are stated where used."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from apr_amd import model, weights as W
+from apr_amd._capi import AprError, FLAVOUR_GO, FLAVOUR_LIBROSA, WARN_OVERFLOW, WARN_UNDERFLOW
+from conftest import GOLDEN, LABELS
+
+pytestmark = pytest.mark.gpu
+
+# fp32 front end vs the f64 reference restatement: spectrogram values live in [0,1]
+SPEC_TOL = 2e-5
+# fp32 CNN, different summation order (K up to 9216): logits are O(1)
+LOGIT_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def fe():
+    e = model.Engine(None, 0, 64)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng(he_weights):
+    e = model.Engine(W.pack_blob(he_weights, 4), 0, 64)
+    yield e
+    e.close()
+
+
+def test_prepare_silence_known_answer(fe):
+    # KA1 (model_test.go:28 input): 1.0 in cols 0..183, 0.0 in cols 184..187
+    out, warn = fe.prepare(np.zeros(192000, np.uint8))
+    assert warn == 0 and out.shape == (128, 188)
+    assert np.all(out[:, :184] == 1.0) and np.all(out[:, 184:] == 0.0)
+
+
+def test_prepare_dimensions_like_reference():
+    # TestPrepare_Dimensions (model_test.go:26-51)
+    t = model.Prepare(bytes(192000))
+    assert t.shape == (1, 1, model.Nmels, model.SpectrogramFrames) and t.dtype == np.float32
+
+
+@pytest.mark.parametrize("name", ["test_empty", "test_smalldog", "test_bigdog", "test_combo"])
+def test_prepare_matches_oracle_on_reference_clips(fe, clips, name):
+    got, _ = fe.prepare(clips[name])
+    want, _ = oracle.prepare_go(clips[name])
+    assert np.abs(got - want).max() <= SPEC_TOL
+
+
+def test_prepare_ramp_and_synth(fe, ramp_pcm):
+    got, _ = fe.prepare(ramp_pcm)
+    want, _ = oracle.prepare_go(ramp_pcm)
+    assert np.abs(got - want).max() <= SPEC_TOL
+    pcm = model.synth_pcm(7, 3, 12)
+    n = model.windows_in(pcm.nbytes)
+    assert n == 11
+    got = fe.prepare_batch(pcm, n)
+    want = oracle.prepare_go_batch(pcm, n)
+    assert np.abs(got - want).max() <= SPEC_TOL
+
+
+def test_prepare_pad_truncate(fe, clips):
+    pcm = clips["test_bigdog"]
+    short, w = fe.prepare(pcm[:100001])          # odd length: lone low byte + zero high byte
+    assert w == WARN_UNDERFLOW
+    want, ow = oracle.prepare_go(pcm[:100001])
+    assert ow == oracle.WARN_UNDERFLOW and np.abs(short - want).max() <= SPEC_TOL
+    padded = np.concatenate([pcm[:100001], np.zeros(192000 - 100001, np.uint8)])
+    assert np.array_equal(short, fe.prepare(padded)[0])            # KA2: identical to zero-padded input
+    long_, w = fe.prepare(np.concatenate([pcm, pcm[:5000]]))
+    assert w == WARN_OVERFLOW and np.array_equal(long_, fe.prepare(pcm)[0])
+    empty, w = fe.prepare(np.zeros(0, np.uint8))
+    assert w == WARN_UNDERFLOW and np.all(empty[:, :184] == 1.0)
+
+
+def test_prepare_unaligned_and_ragged_windows(fe):
+    pcm = model.synth_pcm(1, 0, 5).view(np.uint8)
+    buf = pcm[: 4 * 96000 + 30001]                 # ragged tail: last window short
+    n = 4
+    for stride in (96000, 96002, 50001):           # 4-aligned, 2-aligned, odd (byte path)
+        got = fe.prepare_batch(buf, n, stride)
+        want = oracle.prepare_go_batch(buf, n, stride)
+        assert np.abs(got - want).max() <= SPEC_TOL, stride
+
+
+def test_prepare_librosa_flavour(fe, clips):
+    # parity UNPINNED against librosa itself (absent); checks the HIP path against the restatement
+    for name in ("test_bigdog", "test_empty"):
+        got, _ = fe.prepare(clips[name], FLAVOUR_LIBROSA)
+        want = oracle.prepare_librosa(oracle.normalize_audio(clips[name]))
+        assert want.shape == (128, 188)
+        assert np.abs(got - want).max() <= 5e-5
+    sil, _ = fe.prepare(np.zeros(192000, np.uint8), FLAVOUR_LIBROSA)
+    assert np.all(sil == 1.0)
+
+
+def test_infer_matches_golden_reference_logits(eng):
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))     # from ai.model.NoiseDetector
+    got = eng.infer_logits(specs)
+    assert np.abs(got - want).max() <= LOGIT_TOL
+
+
+def test_infer_torch_default_init_golden():
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_torch_seed1.npy"))
+    e = model.Engine(W.pack_blob(W.random_init(4, 1, "torch"), 4), 0, 8)
+    got = e.infer_logits(specs)
+    e.close()
+    assert np.abs(got - want).max() <= 1e-6     # activations shrink ~1e-5 under torch's default init
+
+
+def test_onnx_folded_and_unfolded_equal_blob(eng, he_weights):
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))[:3]
+    base = eng.infer_logits(specs)
+    for fold, raw in ((True, True), (False, True), (False, False)):
+        e = model.Engine(W.write_onnx(he_weights, 4, fold_bn=fold, raw=raw), 0, 8)
+        got = e.infer_logits(specs)
+        e.close()
+        assert np.abs(got - base).max() <= 2e-5, (fold, raw)
+
+
+def test_reference_style_infer_on_clips(eng, he_weights, clips, tmp_path):
+    # the shape of testMultiClass_Inference (model_test.go:74-147) with random-init weights
+    (tmp_path / "m.onnx").write_bytes(W.write_onnx(he_weights, 4))
+    (tmp_path / "m.labels").write_text('["big_dog", "combination", "empty", "small_dog"]')
+    m = model.Load(str(tmp_path / "m.onnx"))
+    assert m.Labels == LABELS
+    for name, pcm in clips.items():
+        res = model.Infer(m, model.Prepare(pcm.tobytes()))
+        assert set(res) == set(LABELS)
+        assert 0.99 <= sum(res.values()) <= 1.01
+        ologits = oracle.cnn_forward(he_weights, 4, oracle.prepare_go(pcm)[0][None])[0]
+        oprobs = oracle.softmax(ologits)
+        for i, lab in enumerate(LABELS):
+            assert abs(res[lab] - oprobs[i]) <= 1e-4
+        assert max(res, key=res.get) == LABELS[int(np.argmax(oprobs))]
+
+
+def test_score_matches_oracle_labels(eng, he_weights):
+    pcm = model.synth_pcm(0, 0, 20)
+    n = model.windows_in(pcm.nbytes)
+    empty = LABELS.index("empty")
+    got = eng.score(pcm, n, trust=0.5, empty_class=empty)
+    want = oracle.score(he_weights, 4, pcm, n, trust=0.5, empty_class=empty)
+    assert np.abs(got["probs"] - want["probs"]).max() <= 1e-4
+    srt = np.sort(want["logits"], axis=1)
+    decided = (srt[:, -1] - srt[:, -2]) > 2 * LOGIT_TOL          # windows that are not near-ties
+    assert decided.sum() >= n - 1
+    assert np.array_equal(got["label"][decided], want["label"][decided])
+    near = np.abs(want["probs"].max(axis=1) - 0.5) < 1e-3
+    assert np.array_equal(got["match"][decided & ~near], want["match"][decided & ~near])
+
+
+def test_score_chunking_is_invisible(he_weights):
+    pcm = model.synth_pcm(3, 1, 14)
+    n = model.windows_in(pcm.nbytes)
+    a = model.Engine(W.pack_blob(he_weights, 4), 0, 64).score(pcm, n)
+    b = model.Engine(W.pack_blob(he_weights, 4), 0, 5).score(pcm, n)   # 13 windows in chunks of 5
+    assert np.array_equal(a["label"], b["label"]) and np.array_equal(a["probs"], b["probs"])
+
+
+def test_errors_are_codes_not_crashes(fe):
+    with pytest.raises(AprError) as ei:
+        fe.infer_logits(np.zeros((1, 128, 188), np.float32))
+    assert ei.value.code == -5
+    with pytest.raises(AprError):
+        model.Engine(b"not a model", 0, 8)
+    with pytest.raises(AprError):
+        model.Engine(None, 999, 8)
+    out = fe.prepare_batch(np.zeros(10, np.uint8), 0)
+    assert out.shape == (0, 128, 188)
