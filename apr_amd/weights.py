@@ -120,6 +120,14 @@ def random_init(n_classes: int, seed: int = 0, init: str = "he") -> np.ndarray:
     return flat
 
 
+def center_logits(flat: np.ndarray, n_classes: int, mean_logits) -> np.ndarray:
+    """Return a copy with ``mean_logits`` subtracted from the classifier bias (so that a
+    random-init net's argmax varies from window to window instead of sitting on one class)."""
+    out = np.array(flat, dtype=np.float32, copy=True)
+    out[-n_classes:] -= np.asarray(mean_logits, np.float32)
+    return out
+
+
 def pack_blob(flat: np.ndarray, n_classes: int) -> bytes:
     flat = np.ascontiguousarray(flat, dtype="<f4")
     if flat.size != blob_floats(n_classes):
