@@ -1,0 +1,133 @@
+"""CPU: host logic of the product (no compute calls): the C-ABI library loads and exports every
+symbol include/apr.h declares, weight containers, the ONNX reader, the mirror of the Go API."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from apr_amd import _capi, model, sweep, weights as W
+from conftest import LABELS, REPO
+
+
+def test_library_exports_every_declared_symbol():
+    L = _capi.lib()
+    hdr = open(os.path.join(REPO, "include", "apr.h")).read()
+    declared = set(re.findall(r"\b(apr_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"apr_profile_slot"}
+    assert declared == set(_capi.SYMBOLS)
+    for sym in declared:
+        assert getattr(L, sym) is not None
+    assert b"gfx950" in L.apr_version()
+
+
+def test_profile_slot_layout_matches_header():
+    import ctypes
+    assert ctypes.sizeof(_capi.ProfileSlot) == 48 + 8 + 8 + 8 + 8 + 8
+
+
+def test_constants_match_reference():
+    # src/model/model.go:23-40, src/ffmpeg/ffmpeg.go:20-21
+    assert (model.SampleRate, model.BytesPerSecond, model.SegmentSize, model.SampleSize) == (48000, 96000, 2, 192000)
+    assert (model.Nmels, model.Nfft, model.HopLength, model.SpectrogramFrames) == (128, 2048, 512, 188)
+    assert model.Int16Max == 32768.0 and model.MaxFreq == 24000.0 and model.MinFreq == 0.0
+
+
+def test_blob_and_onnx_parse(he_weights):
+    # 23 542 912 conv weights+biases + 4 BatchNorm vectors per layer + classifier
+    assert W.blob_floats(4) == 23542912 + 4 * sum(W.LAYER_COUT) + 4 * 1024 + 4
+    blob = W.pack_blob(he_weights, 4)
+    flat, nc = W.unpack_blob(blob)
+    assert nc == 4 and np.array_equal(flat, he_weights)
+    assert model.model_info(blob) == (4, 12)
+    for fold, raw in ((True, True), (False, True), (False, False)):
+        assert model.model_info(W.write_onnx(he_weights, 4, fold, raw)) == (4, 12)
+    sd = W.to_state_dict(he_weights, 4)
+    assert len(sd) == 12 * 6 + 2 and np.array_equal(W.from_state_dict(sd, 4), he_weights)
+
+
+@pytest.mark.parametrize("bad", [b"", b"garbage!", b"APRW" + b"\0" * 12, b"\x08\x08\x12\x03abc"])
+def test_bad_models_are_error_codes(bad):
+    with pytest.raises(_capi.AprError) as ei:
+        model.model_info(bad)
+    assert ei.value.code == _capi.ERR_MODEL
+
+
+def test_truncated_and_wrong_graphs_rejected(he_weights):
+    onnx = W.write_onnx(he_weights, 4)
+    with pytest.raises(_capi.AprError):
+        model.model_info(onnx[: len(onnx) // 2])
+    with pytest.raises(_capi.AprError):
+        model.model_info(W.pack_blob(he_weights, 4)[:-4])
+
+
+def test_load_reads_onnx_and_labels_and_dies_like_the_reference(tmp_path, capsys):
+    (tmp_path / "whistle.onnx").write_bytes(b"xyz")
+    (tmp_path / "whistle.labels").write_text('["big_dog", "combination", "empty", "small_dog"]')
+    m = model.Load(str(tmp_path / "whistle.onnx"))
+    assert m.RawBytes == b"xyz" and m.Labels == LABELS
+    with pytest.raises(SystemExit) as ei:           # log.Die -> exit status 1 (src/log/log.go:42-46)
+        model.Load(str(tmp_path / "missing.onnx"))
+    assert ei.value.code == 1 and "[ERROR]\t could not read ONNX file" in capsys.readouterr().err
+    (tmp_path / "nolabels.onnx").write_bytes(b"x")
+    with pytest.raises(SystemExit):
+        model.Load(str(tmp_path / "nolabels.onnx"))
+    assert "could not read Labels file" in capsys.readouterr().err
+    (tmp_path / "bad.onnx").write_bytes(b"x")
+    (tmp_path / "bad.labels").write_text("{not json")
+    with pytest.raises(SystemExit):
+        model.Load(str(tmp_path / "bad.onnx"))
+    assert "could not parse Labels JSON" in capsys.readouterr().err
+
+
+def test_softmax_and_decide_mirror():
+    import oracle
+    lg = [float(v) for v in np.array([0.3, -1.2, 2.5, 0.0], np.float32)]   # logits are f32 (model.go:212-216)
+    assert np.allclose(model.softmax(lg), oracle.softmax(lg), rtol=0, atol=1e-16)
+    assert model.decide({"empty": 0.9, "small_dog": 0.1}, 0.5) == ("empty", 0.9, False)
+    assert model.decide({"empty": 0.1, "small_dog": 0.9}, 0.5) == ("small_dog", 0.9, True)
+    assert model.decide({"empty": 0.5, "small_dog": 0.5}, 0.5)[2] is False
+
+
+def test_window_arithmetic_matches_inspect_py():
+    bps = 96000
+    for nbytes in (0, 1, bps, bps + 1, 2 * bps, 2 * bps + 5, 600 * bps):
+        assert sweep.windows_in(nbytes) == len(range(0, nbytes - bps, bps)) == model.windows_in(nbytes)
+    assert sweep.windows_in(600 * bps) == 599 and sweep.windows_in(36000 * bps) == 35999
+
+
+def test_stream_plan_and_match_lines():
+    plan = sweep.plan_stream([3 * 96000, 4 * 96000], [10, 11])
+    assert plan.n_windows == 6 and plan.n_valid == 5
+    assert plan.valid.tolist() == [True, True, False, True, True, True]
+    assert plan.second.tolist() == [0, 1, 2, 0, 1, 2] and plan.file_ids.tolist() == [10, 10, 10, 11, 11, 11]
+    label = np.array([3, 2, 0, 0, -1, 1], np.int32)
+    lines = sweep.format_matches("dogs", LABELS, {10: "a.mkv", 11: "b.mkv"}, plan, label)
+    assert lines == ["Matched dogs/small_dog in a.mkv @1 sec", "Matched dogs/big_dog in b.mkv @1 sec",
+                     "Matched dogs/combination in b.mkv @3 sec"]
+    match = np.array([0, 1, 1, 1, 1, 0], np.uint8)
+    assert sweep.format_matches("dogs", LABELS, {10: "a.mkv", 11: "b.mkv"}, plan, label, match) == \
+        ["Matched dogs/big_dog in b.mkv @1 sec"]
+    assert sweep.daemon_match_line("dogs", "big_dog", 0.98765) == \
+        "[INFO]\t SCANNER dogs: MATCH found! Class: big_dog (Conf: 0.9877)"
+    with pytest.raises(ValueError):
+        sweep.plan_stream([96000 + 1])
+
+
+def test_shard_files_round_robin():
+    assert sweep.shard_files(10, 4, 1) == [1, 5, 9]
+    allf = sorted(sum((sweep.shard_files(61, 8, r) for r in range(8)), []))
+    assert allf == list(range(61))
+
+
+def test_synth_pcm_deterministic_and_seekable():
+    a = model.synth_pcm(5, 2, 6)
+    b = model.synth_pcm(5, 2, 3, second_offset=3)
+    assert a.dtype == np.int16 and a.size == 6 * 48000
+    assert np.array_equal(a[3 * 48000:], b)
+    assert not np.array_equal(a, model.synth_pcm(5, 3, 6))
+    spec = np.abs(np.fft.rfft(a[:48000].astype(np.float64)))
+    assert (spec[8000:] ** 2).sum() / (spec ** 2).sum() < 0.1        # 16 kHz-band content (x3 linear interpolation images only)
+    long = model.synth_pcm(0, 0, 200)
+    zero_run = np.max(np.diff(np.nonzero(np.concatenate([[1], long != 0, [1]]))[0]))
+    assert zero_run >= 2400                              # exact-zero stretches exist

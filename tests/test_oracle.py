@@ -1,0 +1,140 @@
+"""CPU: the oracle against the golden vectors (from the reference's own NoiseDetector) and the
+hand-derivable known answers of SURVEY 8(c).  No GPU, no product code under test here."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from apr_amd import weights as W
+from conftest import GOLDEN
+
+
+def test_KA6_normalize_audio_matches_reference_fixture():
+    # fixture produced by the reference's ai.model.normalize_audio (ai/model.py:163-168)
+    pcm = np.array([-32768, -1, 0, 1, 32767, 12345], dtype="<i2").tobytes()
+    want = np.load(os.path.join(GOLDEN, "normalize_audio.npy"))
+    got = oracle.normalize_audio(pcm)
+    assert np.array_equal(got, want)
+    assert got[0] == -1.0 and got[2] == 0.0 and got[4] == np.float32(32767 / 32768)
+
+
+def test_KA1_silence():
+    out, warn = oracle.prepare_go(np.zeros(192000, np.uint8))
+    assert warn == 0
+    assert np.all(out[:, :184] == 1.0) and np.all(out[:, 184:] == 0.0)
+
+
+def test_KA2_short_equals_zero_padded_long_equals_truncated(clips):
+    pcm = clips["test_combo"]
+    a, wa = oracle.prepare_go(pcm[:77777])
+    b, wb = oracle.prepare_go(np.concatenate([pcm[:77777], np.zeros(192000 - 77777, np.uint8)]))
+    assert wa == oracle.WARN_UNDERFLOW and wb == 0 and np.array_equal(a, b)
+    c, wc = oracle.prepare_go(np.concatenate([pcm, pcm]))
+    assert wc == oracle.WARN_OVERFLOW and np.array_equal(c, oracle.prepare_go(pcm)[0])
+
+
+def test_KA5_mel_lens_integers():
+    w, bounds, pts = oracle.mel_lens()
+    assert pts[:20].tolist() == [0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 15, 16, 17, 19, 20]
+    assert pts[-5:].tolist() == [914, 940, 967, 995, 1024]
+    assert int((w != 0).sum()) == 1892
+    assert int((bounds[:, 1] - bounds[:, 0]).max()) == 57
+    assert int(((w != 0).sum(axis=1) == 0).sum()) == 0
+    assert np.all(w[:, 1024] == 0)                 # bin 1024 never weighted (loops are `< end`)
+    assert w.max() == 1.0                          # unnormalised peak 1.0
+    # falling edge includes the centre bin with weight 1, rising edge starts at 0 (dsp.go:70-78)
+    m = 50
+    assert w[m, pts[m + 1]] == 1.0 and w[m, pts[m]] == 0.0
+
+
+def test_KA3_full_scale_dc():
+    # DC -> Hann-windowed energy in bins 0..1 only; bands covering bins 0/1 carry everything
+    pcm = np.full(96000, 32767, dtype="<i2").view(np.uint8)
+    out, _, power, mel = oracle.prepare_go(pcm, stages=True)
+    col = power[:, 0]
+    # the symmetric (L-1) Hann of go-dsp is not exactly periodic: bin 2 leaks at ~ -76 dB
+    assert col[0] > 0 and col[2] / col[0] < 1e-7
+    hann = oracle.hann()[0]
+    x = np.float64(np.float32(32767) / np.float32(32768))
+    assert np.isclose(col[0], (x * hann.sum()) ** 2, rtol=1e-12)
+    assert np.isclose(col[1] / col[0], 0.25, rtol=2e-3)       # Hann leakage: X[1] ~ -X[0]/2
+    assert out[:, :184].max() == 1.0
+    # band 0 = bin 0 (weight 1) -> 0 dB -> 1.0; band 1 = bin 1 -> 10*log10(0.2504) = -6.01 dB
+    assert out[0, 0] == 1.0 and abs(out[1, 0] - (80 + 10 * np.log10(col[1] / col[0])) / 80) < 1e-6
+    assert np.all(out[3:, :184] == 0.0)                        # everything else is below the -80 dB floor
+
+
+def test_KA4_bin_centred_sine():
+    k = 200                                                    # f = 48000*k/2048 = 4687.5 Hz
+    n = np.arange(96000)
+    s = np.round(16000 * np.sin(2 * np.pi * k * n / 2048)).astype("<i2")
+    out, _, power, mel = oracle.prepare_go(s.view(np.uint8), stages=True)
+    col = power[:, 10]
+    assert int(np.argmax(col)) == k
+    assert np.isclose(col[k - 1] / col[k], 0.25, rtol=2e-3) and np.isclose(col[k + 1] / col[k], 0.25, rtol=2e-3)
+    assert col[k + 3] / col[k] < 1e-6
+    _, bounds, _ = oracle.mel_lens()
+    covering = [m for m in range(128) if bounds[m, 0] <= k < bounds[m, 1]]
+    assert int(np.argmax(mel[:, 10])) in covering
+
+
+def test_numpy_cross_check_of_the_go_front_end(clips, ramp_pcm):
+    # independent formulation (numpy FFT, dense lens matmul); not a pin of the reference itself
+    w, _, _ = oracle.mel_lens()
+    hann = 0.5 * (1 - np.cos(2 * np.pi * np.arange(2048) / 2047))
+    for pcm in (clips["test_bigdog"], clips["test_empty"], ramp_pcm):
+        x = (pcm.view("<i2").astype(np.float32) / np.float32(32768)).astype(np.float64)
+        fr = np.stack([x[512 * i:512 * i + 2048] * hann for i in range(184)])
+        P = (np.abs(np.fft.fft(fr, axis=1))[:, :1025] ** 2).T
+        M = w @ P
+        db = 10 * np.log10(np.maximum(M, 1e-10) / max(1e-10, M.max()))
+        ref = ((np.clip(db, -80, 0) + 80) / 80).astype(np.float32)
+        out, _ = oracle.prepare_go(pcm)
+        assert np.abs(out[:, :184] - ref).max() < 1e-6 and np.all(out[:, 184:] == 0)
+
+
+def test_librosa_flavour_restatement_properties(clips):
+    # parity UNPINNED (librosa absent): structural checks only
+    basis = oracle.librosa_mel_basis()
+    assert basis.shape == (128, 1025) and basis.dtype == np.float32
+    assert np.all(basis >= 0) and np.all((basis != 0).sum(axis=1) > 0)
+    _, pts_go = oracle.mel_lens()[1], None
+    out = oracle.prepare_librosa(oracle.normalize_audio(clips["test_smalldog"]))
+    assert out.shape == (128, 188) and out.min() >= 0.0 and out.max() == 1.0
+    assert np.all(oracle.prepare_librosa(np.zeros(96000, np.float32)) == 1.0)
+    # the two reference flavours really are different functions
+    go, _ = oracle.prepare_go(clips["test_smalldog"])
+    assert np.abs(go[:, 2:182] - out[:, 4:184]).max() > 1e-3
+
+
+@pytest.mark.parametrize("init,seed,tol", [("he", 0, 2e-4), ("torch", 1, 1e-6)])
+def test_cnn_matches_reference_noisedetector_golden(init, seed, tol):
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, f"cnn_logits_{init}_seed{seed}.npy"))
+    flat = W.random_init(4, seed, init)
+    got = oracle.cnn_forward(flat, 4, specs)
+    assert np.abs(got - want).max() <= tol
+    pooled = np.load(os.path.join(GOLDEN, f"cnn_pooled_{init}_seed{seed}.npy"))
+    _, feat = oracle.cnn_forward_feat(flat, 4, specs[2])
+    assert np.abs(feat - pooled[2]).max() <= tol * max(1.0, float(np.abs(pooled[2]).max()))
+
+
+def test_KA7_softmax_and_decision():
+    p = oracle.softmax(np.array([1.5, 1.5, 1.5, 1.5], np.float32))
+    assert np.allclose(p, 0.25) and abs(p.sum() - 1) < 1e-15
+    p = oracle.softmax(np.array([1000.0, 0.0, -1000.0], np.float32))
+    assert p[0] == 1.0 and p[2] == 0.0
+    # daemon.go:203: match iff best != "empty" and conf > trust (strict)
+    assert oracle.decide([0.2, 0.5, 0.3], 2, 0.5) == (1, 0.5, False)
+    assert oracle.decide([0.2, 0.6, 0.2], 2, 0.5) == (1, 0.6, True)
+    assert oracle.decide([0.2, 0.1, 0.7], 2, 0.5) == (2, 0.7, False)
+    assert oracle.decide([0.0, 0.0, 0.0], 2, 0.5)[0] == -1
+
+
+def test_score_whole_path_consistency(he_weights, clips):
+    pcm = np.concatenate([clips["test_bigdog"], clips["test_combo"][:96000]])   # 3 s -> 2 windows
+    r = oracle.score(he_weights, 4, pcm, 2, trust=0.5, empty_class=2, want_spec=True)
+    assert np.array_equal(r["spec"][0], oracle.prepare_go(clips["test_bigdog"])[0])
+    assert np.allclose(r["probs"].sum(axis=1), 1.0)
+    assert np.array_equal(r["label"], r["logits"].argmax(axis=1))
