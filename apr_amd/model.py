@@ -5,7 +5,7 @@ constants (model.go:23-40), ``OnnxModel`` (model.go:43-46), ``Train`` (model.go:
 ``Load`` (model.go:54-83), ``Prepare`` (model.go:86-184), ``Infer`` (model.go:188-229),
 plus the batch entry points the sweep uses (``Engine.score`` ...).  The Go toolchain is
 absent in the build image, so this Python module is what the parity tests drive; the
-cgo shim a maintainer would add is shown in INTEGRATION.md and go/model/model.go.
+cgo shim a maintainer would add is shown in INTEGRATION.md and go/model/apr_cgo.go.
 
 All arithmetic runs in libapr_amd.so on the GPU.  There is no CPU fallback.
 """
