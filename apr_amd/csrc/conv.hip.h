@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
                                                             const float *__restrict__ wt,
                                                             const float *__restrict__ bias,
                                                             float *__restrict__ out, int H, int W, int Cin,
-                                                            int Ho, int Wo, int Cout, int M, int tiles_n)
+                                                            int Ho, int Wo, int Cout, int M, int tiles_n,
+                                                            const float *__restrict__ zeros /* >= 16 B of 0.0f */)
 {
     constexpr int BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -133,21 +134,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const int cchunks = Cin >> 5;
     const int KT = 9 * cchunks;
 
-    // Loads are unconditional (out-of-image taps read element 0 and are zeroed when staged to
-    // LDS): a branch around a load would make hipcc wait for every load separately.
+    // Loads are unconditional: out-of-image taps (zero padding) and rows past M read from a
+    // small zero buffer instead, so the loaded registers go to LDS untouched.  (A branch around
+    // a load makes hipcc wait for every load separately; a select on the loaded value lets it
+    // hoist that select, and the vmcnt wait with it, right behind the load.)
     f32x4 ra[AROWS], rb[BPASS];
-    unsigned okbits = 0;
 #define APR_LOAD_TILES(KT_)                                                                              \
     {                                                                                                    \
         const int tap_ = (KT_) / cchunks;                                                                \
         const int c0_ = ((KT_) - tap_ * cchunks) << 5;                                                   \
         const long long tapoff_ = ((long long)(tap_ / 3) * W + (tap_ % 3)) * Cin + c0_;                  \
-        okbits = 0;                                                                                      \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
             const bool ok_ = (rowmask[i] >> tap_) & 1u;                                                  \
-            okbits |= (ok_ ? 1u : 0u) << i;                                                              \
-            ra[i] = *reinterpret_cast<const f32x4 *>(in + (ok_ ? rowbase[i] + tapoff_ : 0ll));          \
+            const float *src_ = ok_ ? in + (rowbase[i] + tapoff_) : zeros;                               \
+            ra[i] = *reinterpret_cast<const f32x4 *>(src_);                                              \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                                \
             rb[i] = *reinterpret_cast<const f32x4 *>(wcol + (size_t)((KT_) * BK + brow0 + BROWS * i) * Cout); \
@@ -158,11 +159,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
             const int rr_ = ar0 + 32 * i;                                                                \
-            const bool ok_ = (okbits >> i) & 1u;                                                         \
-            a_[(ac * 4 + 0) * LDA + rr_] = ok_ ? ra[i].x : 0.0f;                                         \
-            a_[(ac * 4 + 1) * LDA + rr_] = ok_ ? ra[i].y : 0.0f;                                         \
-            a_[(ac * 4 + 2) * LDA + rr_] = ok_ ? ra[i].z : 0.0f;                                         \
-            a_[(ac * 4 + 3) * LDA + rr_] = ok_ ? ra[i].w : 0.0f;                                         \
+            a_[(ac * 4 + 0) * LDA + rr_] = ra[i].x;                                                      \
+            a_[(ac * 4 + 1) * LDA + rr_] = ra[i].y;                                                      \
+            a_[(ac * 4 + 2) * LDA + rr_] = ra[i].z;                                                      \
+            a_[(ac * 4 + 3) * LDA + rr_] = ra[i].w;                                                      \
         }                                                                                                \
         float *b_ = Bs[BUF_];                                                                            \
         _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                                \
@@ -181,29 +181,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     APR_STORE_TILES(0)
     __syncthreads();
 
-    int cur = 0;
-    for (int kt = 0; kt < KT; kt++) {
-        if (kt + 1 < KT) APR_LOAD_TILES(kt + 1)
-        const float *a = As[cur] + wm * WM + li;
-        const float *b = Bs[cur] + wn * WN + li;
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; kk++) {
-            const int k = 2 * kk + half;
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = a[k * LDA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = b[k * BN + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < KT) APR_STORE_TILES(cur ^ 1)
-        __syncthreads();
-        cur ^= 1;
+    // Main loop.  Everything that is not an MFMA is placed in the shadow of the MFMAs: operand
+    // fragments are read one k-pair ahead (two register sets), the next tile's global loads are
+    // issued after the first k-pair and staged to the other LDS buffer late in the step (that
+    // buffer was released by the barrier that ended the previous step).  hipcc would otherwise
+    // sink every ds_read next to its MFMA (lgkmcnt(0) before each group), so LDS reads and
+    // MFMAs are fenced per k-pair; only VALU/SALU may still move (mask 0x6).
+#define APR_KSTEP(HAS_NEXT)                                                                              \
+    {                                                                                                    \
+        const float *a = As[cur] + wm * WM + li;                                                         \
+        const float *b = Bs[cur] + wn * WN + li;                                                         \
+        float af[2][TM], bf[2][TN];                                                                      \
+        _Pragma("unroll") for (int i = 0; i < TM; i++) af[0][i] = a[half * LDA + i * 32];                \
+        _Pragma("unroll") for (int j = 0; j < TN; j++) bf[0][j] = b[half * BN + j * 32];                 \
+        _Pragma("unroll") for (int kk = 0; kk < BK / 2; kk++)                                            \
+        {                                                                                                \
+            if (kk + 1 < BK / 2) {                                                                       \
+                const int k = 2 * (kk + 1) + half;                                                       \
+                _Pragma("unroll") for (int i = 0; i < TM; i++) af[(kk + 1) & 1][i] = a[k * LDA + i * 32]; \
+                _Pragma("unroll") for (int j = 0; j < TN; j++) bf[(kk + 1) & 1][j] = b[k * BN + j * 32]; \
+            }                                                                                            \
+            __builtin_amdgcn_sched_barrier(0x6);                                                         \
+            if (HAS_NEXT && kk == 1) APR_LOAD_TILES(kt + 1)                                              \
+            if (HAS_NEXT && kk == BK / 2 - 4) APR_STORE_TILES(cur ^ 1)                                   \
+            _Pragma("unroll") for (int i = 0; i < TM; i++)                                               \
+                _Pragma("unroll") for (int j = 0; j < TN; j++)                                           \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0x6);                                                         \
+        }                                                                                                \
+        __syncthreads();                                                                                 \
+        cur ^= 1;                                                                                        \
     }
+
+    int cur = 0;
+    int kt = 0;
+    for (; kt < KT - 1; kt++) APR_KSTEP(true)
+    APR_KSTEP(false)
+#undef APR_KSTEP
 
     // ---- epilogue: bias + ReLU, NHWC store.  D[row][col]: col = lane&31,
     //      row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----

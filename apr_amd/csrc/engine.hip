@@ -55,6 +55,7 @@ struct apr_engine {
     std::vector<Layer> layers;
     float *d_act[2] = {nullptr, nullptr};
     float *d_wfc = nullptr, *d_bfc = nullptr;
+    float *d_zeros = nullptr;     // 256 B of 0.0f: source of the convolutions' zero padding
 
     // staging for the host-pointer entry points
     uint8_t *d_pcm = nullptr;
@@ -250,6 +251,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     if ((rc = dev_upload(e, &e->d_wfc, pm.fc_w)) || (rc = dev_upload(e, &e->d_bfc, pm.fc_b))) return rc;
     for (int i = 0; i < 2; i++)
         if ((rc = dev_alloc(e, &e->d_act[i], act_max * (size_t)e->max_batch))) return rc;
+    if ((rc = dev_upload(e, &e->d_zeros, std::vector<float>(64, 0.0f)))) return rc;
     return APR_OK;
 }
 
@@ -325,7 +327,7 @@ void launch_igemm(apr_engine *e, const Layer &L, const float *in, float *out, lo
     const int tiles_n = L.cout / BN;
     const long long tiles_m = (M + BM - 1) / BM;   // M < 2^31: max_batch is capped at create
     hipLaunchKernelGGL((conv3x3_igemm_f32<BM, BN, S>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, e->stream, in,
-                       L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n);
+                       L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n, e->d_zeros);
 }
 
 int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class, float *d_logits, double *d_probs,
