@@ -16,6 +16,26 @@
 
 namespace apr {
 
+// developer knobs for tools/igemm_bench.cpp (timing-only ablations; both must be 1 in the product)
+#ifndef APR_EXP_STAGE
+#define APR_EXP_STAGE 1
+#endif
+#ifndef APR_EXP_LOAD
+#define APR_EXP_LOAD 1
+#endif
+#ifndef APR_EXP_STORE
+#define APR_EXP_STORE 1
+#endif
+#ifndef APR_EXP_ST0
+#define APR_EXP_ST0 5
+#endif
+#ifndef APR_EXP_BDMA
+#define APR_EXP_BDMA 1
+#endif
+#ifndef APR_EXP_SYNC
+#define APR_EXP_SYNC 1
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,6 +78,24 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ sp
     }
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA: 64 lanes x 16 B from a buffer (descriptor rs, per-lane byte offset voff, scalar byte
+// offset soff) to 1 KiB of LDS starting at byte address lds_base (wave-uniform).  Inline asm on
+// purpose: hipcc makes every later ds_read wait vmcnt(0) behind a builtin LDS-DMA (it cannot
+// tell the DMA's target from the buffer being read), which would serialise the whole K step.
+// The caller waits (s_waitcnt vmcnt(0)) before the barrier that publishes the tile.  hipcc's
+// own counted vmcnt waits do not see these loads and therefore only ever wait for MORE.
+__device__ __forceinline__ void lds_dma_b128(i32x4 rs, unsigned voff, int soff, unsigned lds_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(lds_base), "s"(soff)
+                 : "memory");
+}
+
 // ---------------------------------------------------------------------------------------------
 // Implicit-GEMM 3x3 convolution, pad 1, stride STRIDE, NHWC, fp32 MFMA.
 //   M = B*Ho*Wo output pixels, N = Cout, K = 9*Cin (k = tap*Cin + cin).
@@ -74,8 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
                                                             const float *__restrict__ wt,
                                                             const float *__restrict__ bias,
                                                             float *__restrict__ out, int H, int W, int Cin,
-                                                            int Ho, int Wo, int Cout, int M, int tiles_n,
-                                                            const float *__restrict__ zeros /* >= 16 B of 0.0f */)
+                                                            int Ho, int Wo, int Cout, int M, int tiles_n)
 {
     constexpr int BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -85,7 +122,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     constexpr int BROWS = 256 / BCH;
     constexpr int BPASS = BK / BROWS;
     constexpr int LDA = BM + 1;
+    constexpr int NK = BK / 2;           // k-pairs (one v_mfma_f32_32x32x2 each) per K step
+    constexpr int ST0 = APR_EXP_ST0;     // first k-pair that stages a piece of the next tile
     static_assert(TM >= 1 && TN >= 1 && BPASS >= 1, "tile too small");
+    static_assert(ST0 + AROWS <= NK && ST0 + BPASS <= NK, "staging does not fit in the K step");
 
     __shared__ float As[2][BK * LDA];
     __shared__ float Bs[2][BK * BN];
@@ -102,22 +142,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const int bn = lid % tiles_n;
     const int bm = lid / tiles_n;
 
-    // ---- A (im2col) load assignment: thread -> 16-B chunk ac of rows ar0 + 32 i ----
-    const int ac = tid & 7, ar0 = tid >> 3;
-    long long rowbase[AROWS];
-    unsigned rowmask[AROWS];
+    // ---- addressing: buffer loads (wave-uniform descriptor + scalar offset per K step + a
+    //      per-lane 32-bit offset fixed for the whole kernel), so a K step costs ~3 VALU per
+    //      load instead of 64-bit pointer arithmetic.  Zero padding and rows past M use an
+    //      out-of-range offset: the buffer unit returns 0 for those lanes.
+    constexpr unsigned OOB = 0x80000000u;            // >= num_records of the A descriptor
+    const int p0 = bm * BM;                          // first output pixel of this block (< M)
+    const long long b0 = (p0 / Wo) / Ho;             // its window
+    // descriptor base = one row and one column before window b0's image, so every valid
+    // tap has a non-negative offset (the base itself may lie before `in`; never dereferenced)
+    const float *abase = in + ((b0 * H - 1) * W - 1) * (long long)Cin;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x40000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(wt + (size_t)bn * BN), 0, 0x7FFFFFFF, 0x00020000);
+
+    const int ac = tid & 7, ar0 = tid >> 3;          // A: 16-B chunk ac of rows ar0 + 32 i
+    unsigned rowoff[AROWS], rowmask[AROWS];
 #pragma unroll
     for (int i = 0; i < AROWS; i++) {
-        const int p = bm * BM + ar0 + 32 * i;   // M < 2^31 (host-checked)
+        const int p = p0 + ar0 + 32 * i;             // M < 2^31 (host-checked)
         rowmask[i] = 0;
-        rowbase[i] = 0;
+        rowoff[i] = OOB;
         if (p < M) {
             const int ow = p % Wo;
             const int t = p / Wo;
             const int oh = t % Ho;
-            const long long b = t / Ho;
+            const int db = t / Ho - (int)b0;         // windows past b0 (small)
             const int ih0 = oh * STRIDE - 1, iw0 = ow * STRIDE - 1;
-            rowbase[i] = ((b * H + ih0) * W + iw0) * (long long)Cin + ac * 4;
+            // element offset from abase: ((db*H + ih0 + 1)*W + iw0 + 1)*Cin + 4 ac   (< 2^28)
+            rowoff[i] = 4u * (unsigned)(((db * H + ih0 + 1) * W + iw0 + 1) * Cin + ac * 4);
             unsigned mk = 0;
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
@@ -127,47 +179,58 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
             rowmask[i] = mk;
         }
     }
-    // ---- B (weights) load assignment ----
-    const int bch = tid % BCH, brow0 = tid / BCH;
-    const float *wcol = wt + (size_t)bn * BN + bch * 4;
+    const int bch = tid % BCH, brow0 = tid / BCH;    // B: 16-B chunk bch of k-rows brow0 + BROWS i
+    unsigned boff[BPASS];
+#pragma unroll
+    for (int i = 0; i < BPASS; i++) boff[i] = 4u * (unsigned)((brow0 + BROWS * i) * Cout + bch * 4);
+    // the same weight descriptor as plain SGPR words for the inline-asm LDS-DMA, and the LDS byte
+    // address of this wave's first k-rows of Bs[0] (low 32 bits of the flat LDS address)
+    const unsigned long long wb = (unsigned long long)(wt + (size_t)bn * BN);
+    i32x4 rsBv;
+    rsBv.x = __builtin_amdgcn_readfirstlane((int)(unsigned)wb);
+    rsBv.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(wb >> 32) & 0xFFFF);
+    rsBv.z = 0x7FFFFFFF;
+    rsBv.w = 0x00020000;
+    const unsigned bs_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(&Bs[0][0] + wave * (64 / BCH) * BN));
 
     const int cchunks = Cin >> 5;
     const int KT = 9 * cchunks;
 
-    // Loads are unconditional: out-of-image taps (zero padding) and rows past M read from a
-    // small zero buffer instead, so the loaded registers go to LDS untouched.  (A branch around
-    // a load makes hipcc wait for every load separately; a select on the loaded value lets it
-    // hoist that select, and the vmcnt wait with it, right behind the load.)
     f32x4 ra[AROWS], rb[BPASS];
 #define APR_LOAD_TILES(KT_)                                                                              \
     {                                                                                                    \
         const int tap_ = (KT_) / cchunks;                                                                \
         const int c0_ = ((KT_) - tap_ * cchunks) << 5;                                                   \
-        const long long tapoff_ = ((long long)(tap_ / 3) * W + (tap_ % 3)) * Cin + c0_;                  \
+        const int soffA_ = 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_);                              \
+        const int soffB_ = 4 * (KT_) * BK * Cout;                                                        \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
-            const bool ok_ = (rowmask[i] >> tap_) & 1u;                                                  \
-            const float *src_ = ok_ ? in + (rowbase[i] + tapoff_) : zeros;                               \
-            ra[i] = *reinterpret_cast<const f32x4 *>(src_);                                              \
+            const unsigned vo_ = ((rowmask[i] >> tap_) & 1u) ? rowoff[i] : OOB;                          \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo_, soffA_, 0)); \
         }                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                                \
-            rb[i] = *reinterpret_cast<const f32x4 *>(wcol + (size_t)((KT_) * BK + brow0 + BROWS * i) * Cout); \
+        if (!APR_EXP_BDMA) {                                                                             \
+            _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                            \
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i], soffB_, 0)); \
+        }                                                                                                \
     }
-#define APR_STORE_TILES(BUF_)                                                                            \
+    // B tile straight into LDS (LDS-DMA, no VGPRs, no ds_write): one wave-instruction writes
+    // 1 KiB = 64 lanes x 16 B contiguously, which is exactly (64/BCH) whole k-rows of Bs.
+#define APR_DMA_B(KT_, BUF_)                                                                             \
     {                                                                                                    \
-        float *a_ = As[BUF_];                                                                            \
-        _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
-        {                                                                                                \
-            const int rr_ = ar0 + 32 * i;                                                                \
-            a_[(ac * 4 + 0) * LDA + rr_] = ra[i].x;                                                      \
-            a_[(ac * 4 + 1) * LDA + rr_] = ra[i].y;                                                      \
-            a_[(ac * 4 + 2) * LDA + rr_] = ra[i].z;                                                      \
-            a_[(ac * 4 + 3) * LDA + rr_] = ra[i].w;                                                      \
-        }                                                                                                \
-        float *b_ = Bs[BUF_];                                                                            \
+        const int soffB_ = 4 * (KT_) * BK * Cout;                                                        \
+        const unsigned lds_ = bs_lds + 4u * (unsigned)((BUF_) * BK * BN);                                \
         _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                                \
-            *reinterpret_cast<f32x4 *>(b_ + (brow0 + BROWS * i) * BN + bch * 4) = rb[i];                \
+            lds_dma_b128(rsBv, boff[i], soffB_, lds_ + 4u * (unsigned)(BROWS * i * BN));                 \
     }
+#define APR_STORE_A(BUF_, I_)                                                                            \
+    {                                                                                                    \
+        float *a_ = As[BUF_] + ar0 + 32 * (I_);                                                          \
+        a_[(ac * 4 + 0) * LDA] = ra[I_].x;                                                               \
+        a_[(ac * 4 + 1) * LDA] = ra[I_].y;                                                               \
+        a_[(ac * 4 + 2) * LDA] = ra[I_].z;                                                               \
+        a_[(ac * 4 + 3) * LDA] = ra[I_].w;                                                               \
+    }
+#define APR_STORE_B(BUF_, I_) *reinterpret_cast<f32x4 *>(Bs[BUF_] + (brow0 + BROWS * (I_)) * BN + bch * 4) = rb[I_];
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -178,15 +241,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
     APR_LOAD_TILES(0)
-    APR_STORE_TILES(0)
+    if (APR_EXP_BDMA) APR_DMA_B(0, 0)
+#pragma unroll
+    for (int i = 0; i < AROWS; i++) APR_STORE_A(0, i)
+    if (!APR_EXP_BDMA) {
+#pragma unroll
+        for (int i = 0; i < BPASS; i++) APR_STORE_B(0, i)
+    }
+    if (APR_EXP_BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Main loop.  Everything that is not an MFMA is placed in the shadow of the MFMAs: operand
-    // fragments are read one k-pair ahead (two register sets), the next tile's global loads are
-    // issued after the first k-pair and staged to the other LDS buffer late in the step (that
-    // buffer was released by the barrier that ended the previous step).  hipcc would otherwise
-    // sink every ds_read next to its MFMA (lgkmcnt(0) before each group), so LDS reads and
-    // MFMAs are fenced per k-pair; only VALU/SALU may still move (mask 0x6).
+    // fragments are read one k-pair ahead (two register sets); the next tile's buffer loads are
+    // issued after the first k-pair and written to the other LDS buffer a piece per k-pair from
+    // ST0 on (that buffer was released by the barrier that ended the previous step).  hipcc
+    // would otherwise sink every ds_read next to its MFMA (lgkmcnt(0) before each group), so
+    // memory instructions and MFMAs are fenced per k-pair; only VALU/SALU may move (mask 0x6).
 #define APR_KSTEP(HAS_NEXT)                                                                              \
     {                                                                                                    \
         const float *a = As[cur] + wm * WM + li;                                                         \
@@ -194,22 +264,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         float af[2][TM], bf[2][TN];                                                                      \
         _Pragma("unroll") for (int i = 0; i < TM; i++) af[0][i] = a[half * LDA + i * 32];                \
         _Pragma("unroll") for (int j = 0; j < TN; j++) bf[0][j] = b[half * BN + j * 32];                 \
-        _Pragma("unroll") for (int kk = 0; kk < BK / 2; kk++)                                            \
+        _Pragma("unroll") for (int kk = 0; kk < NK; kk++)                                                \
         {                                                                                                \
-            if (kk + 1 < BK / 2) {                                                                       \
+            if (kk + 1 < NK) {                                                                           \
                 const int k = 2 * (kk + 1) + half;                                                       \
                 _Pragma("unroll") for (int i = 0; i < TM; i++) af[(kk + 1) & 1][i] = a[k * LDA + i * 32]; \
                 _Pragma("unroll") for (int j = 0; j < TN; j++) bf[(kk + 1) & 1][j] = b[k * BN + j * 32]; \
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0x6);                                                         \
-            if (HAS_NEXT && kk == 1) APR_LOAD_TILES(kt + 1)                                              \
-            if (HAS_NEXT && kk == BK / 2 - 4) APR_STORE_TILES(cur ^ 1)                                   \
+            if (APR_EXP_STAGE && APR_EXP_LOAD && HAS_NEXT && kk == 1) APR_LOAD_TILES(kt + 1)             \
+            if (APR_EXP_STAGE && APR_EXP_BDMA && HAS_NEXT && kk == 2) APR_DMA_B(kt + 1, cur ^ 1)         \
+            if (APR_EXP_STAGE && APR_EXP_STORE && HAS_NEXT && kk >= ST0 && kk < ST0 + AROWS) APR_STORE_A(cur ^ 1, kk - ST0) \
+            if (APR_EXP_STAGE && APR_EXP_STORE && !APR_EXP_BDMA && HAS_NEXT && kk >= ST0 && kk < ST0 + BPASS) APR_STORE_B(cur ^ 1, kk - ST0) \
+            if (APR_EXP_STAGE && !APR_EXP_STORE && HAS_NEXT && kk == ST0) {                              \
+                _Pragma("unroll") for (int i = 0; i < AROWS; i++) asm volatile("" ::"v"(ra[i]));          \
+                if (!APR_EXP_BDMA) { _Pragma("unroll") for (int i = 0; i < BPASS; i++) asm volatile("" ::"v"(rb[i])); } \
+            }                                                                                            \
             _Pragma("unroll") for (int i = 0; i < TM; i++)                                               \
                 _Pragma("unroll") for (int j = 0; j < TN; j++)                                           \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0x6);                                                         \
         }                                                                                                \
-        __syncthreads();                                                                                 \
+        if (APR_EXP_BDMA && HAS_NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
+        if (APR_EXP_SYNC) __syncthreads();                                                               \
         cur ^= 1;                                                                                        \
     }
 
@@ -221,24 +298,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 
     // ---- epilogue: bias + ReLU, NHWC store.  D[row][col]: col = lane&31,
     //      row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+    const bool full = p0 + BM <= M;      // block-uniform: no per-row bounds test for whole tiles
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = bn * BN + wn * WN + j * 32 + li;
         const float bv = bias[n];
 #pragma unroll
         for (int i = 0; i < TM; i++) {
-            const int prow = bm * BM + wm * WM + i * 32 + 4 * half;
+            const int prow = p0 + wm * WM + i * 32 + 4 * half;
+            float *o = out + (long long)prow * Cout + n;
+            if (full) {
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int p = prow + (e & 3) + 8 * (e >> 2);
-                if (p < M) out[(long long)p * Cout + n] = fmaxf(acc[i][j][e] + bv, 0.0f);
+                for (int e = 0; e < 16; e++) o[(long long)((e & 3) + 8 * (e >> 2)) * Cout] = fmaxf(acc[i][j][e] + bv, 0.0f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int p = prow + (e & 3) + 8 * (e >> 2);
+                    if (p < M) out[(long long)p * Cout + n] = fmaxf(acc[i][j][e] + bv, 0.0f);
+                }
             }
         }
     }
 }
 
 #undef APR_LOAD_TILES
-#undef APR_STORE_TILES
+#undef APR_STORE_A
+#undef APR_STORE_B
+#undef APR_DMA_B
 
 // ---------------------------------------------------------------------------------------------
 // head: act [B][P][F] (NHWC, P = 2*3 pixels, F = 1024) -> max over P -> logits = Wfc feat + b

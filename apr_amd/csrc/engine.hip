@@ -327,7 +327,7 @@ void launch_igemm(apr_engine *e, const Layer &L, const float *in, float *out, lo
     const int tiles_n = L.cout / BN;
     const long long tiles_m = (M + BM - 1) / BM;   // M < 2^31: max_batch is capped at create
     hipLaunchKernelGGL((conv3x3_igemm_f32<BM, BN, S>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, e->stream, in,
-                       L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n, e->d_zeros);
+                       L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n);
 }
 
 int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class, float *d_logits, double *d_probs,
