@@ -27,7 +27,7 @@ struct Layer {
     int cin, cout, stride, hin, win, hout, wout;
     float *d_w = nullptr;   // [9][cin][cout]
     float *d_b = nullptr;   // [cout]
-    int bn_tile = 0;
+    int bn_tile = 0, bm_tile = 128;
 };
 
 struct ProfPair {
@@ -234,6 +234,11 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
         } else {
             if (cv.cin % 32 || cv.cout % 64) { e->err = "conv widths must be multiples of 32 (in) / 64 (out)"; return APR_ERR_MODEL; }
             L.bn_tile = cv.cout % 128 == 0 ? 128 : 64;
+            // short grids (late layers: few pixels per window) use 64-row tiles: twice the blocks, at
+            // three blocks per CU, fill the 256 CUs where 128-row tiles leave a partial round.
+            // Decided once from max_batch so that a layer always runs the same instantiation.
+            const long long m_full = (long long)e->max_batch * L.hout * L.wout;
+            if (L.bn_tile == 128 && ((m_full + 127) / 128) * (cv.cout / 128) < 1024) L.bm_tile = 64;
         }
         // re-layout [cout][cin][3][3] -> [tap][cin][cout]
         std::vector<float> wt((size_t)9 * cv.cin * cv.cout);
@@ -347,8 +352,13 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, in, L.d_w, L.d_b, out, L.hin,
                                L.win, M);
         } else if (L.bn_tile == 128) {
-            if (L.stride == 1) launch_igemm<128, 128, 1>(e, L, in, out, M);
-            else launch_igemm<128, 128, 2>(e, L, in, out, M);
+            if (L.bm_tile == 64) {
+                if (L.stride == 1) launch_igemm<64, 128, 1>(e, L, in, out, M);
+                else launch_igemm<64, 128, 2>(e, L, in, out, M);
+            } else {
+                if (L.stride == 1) launch_igemm<128, 128, 1>(e, L, in, out, M);
+                else launch_igemm<128, 128, 2>(e, L, in, out, M);
+            }
         } else {
             if (L.stride == 1) launch_igemm<128, 64, 1>(e, L, in, out, M);
             else launch_igemm<128, 64, 2>(e, L, in, out, M);
@@ -454,7 +464,7 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
             const Layer &L = e->layers[l];
             char nm[48];
             if (l == 0) snprintf(nm, sizeof nm, "conv1_kernel");
-            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<128, %d, %d>", L.bn_tile, L.stride);
+            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d>", L.bm_tile, L.bn_tile, L.stride);
             add_slot(e, nm, (int)l + 1);
         }
         add_slot(e, "head_kernel", -1);
