@@ -154,8 +154,19 @@ def main() -> int:
         tot_ms = sum(a["ms"] for a in fam.values())
         dom_name, dom = max(((k, v) for k, v in fam.items() if "igemm" in k), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
+        # WRITE_SIZE cannot be collected inside this process).  Valid for 1024-window launches only.
+        traffic = None
+        try:
+            if args.max_batch == 1024:
+                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+                    traffic = json.load(fh)["kernels"][dom_name]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         out["roofline"] = {"kernel": dom_name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                           "traffic_unit": "HBM bytes per launch (PMC, FETCH_SIZE x2 + WRITE_SIZE)",
+                           "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
                            "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
                            "share_of_gpu_time": dom["ms"] / tot_ms}
         out["kernels"] = [
