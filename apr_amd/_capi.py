@@ -19,7 +19,7 @@ SYMBOLS = (
     "apr_device_count", "apr_version", "apr_engine_create", "apr_engine_destroy", "apr_engine_num_classes",
     "apr_last_error", "apr_prepare", "apr_prepare_batch", "apr_infer", "apr_score", "apr_score_device",
     "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable",
-    "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info",
+    "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
 )
 
 
@@ -73,6 +73,10 @@ def lib():
     L.apr_prepare_batch_device.restype = C.c_int
     L.apr_infer_device.argtypes = [vp, f32p, C.c_int, f32p]
     L.apr_infer_device.restype = C.c_int
+    L.apr_classify.argtypes = [vp, f32p, C.c_int, C.c_double, C.c_int, f64p, vp, vp, f32p]
+    L.apr_classify.restype = C.c_int
+    L.apr_classify_device.argtypes = [vp, f32p, C.c_int, C.c_double, C.c_int, f64p, vp, vp, f32p]
+    L.apr_classify_device.restype = C.c_int
     L.apr_sync.argtypes = [vp]
     L.apr_sync.restype = C.c_int
     L.apr_engine_stream.argtypes = [vp]

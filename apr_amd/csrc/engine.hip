@@ -583,6 +583,45 @@ int apr_infer(apr_engine *e, const float *spec, int batch, float *out_logits)
     return APR_OK;
 }
 
+int apr_classify_device(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class, double *d_probs,
+                        int32_t *d_label, uint8_t *d_match, float *d_logits)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if (batch < 0 || (batch && !d_spec)) { e->err = "apr_classify_device: bad argument"; return APR_ERR_INVALID; }
+    const int C = e->n_classes;
+    for (int b0 = 0; b0 < batch; b0 += e->max_batch) {
+        const int nb = std::min(e->max_batch, batch - b0);
+        if ((rc = run_cnn(e, d_spec + (size_t)b0 * APR_SPEC_ELEMS, nb, trust, empty_class, d_logits ? d_logits + (size_t)b0 * C : nullptr,
+                          d_probs ? d_probs + (size_t)b0 * C : nullptr, d_label ? d_label + b0 : nullptr, d_match ? d_match + b0 : nullptr)))
+            return rc;
+    }
+    return APR_OK;
+}
+
+int apr_classify(apr_engine *e, const float *spec, int batch, double trust, int empty_class, double *probs, int32_t *label,
+                 uint8_t *match, float *logits)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if (batch < 0 || (batch && !spec)) { e->err = "apr_classify: bad argument"; return APR_ERR_INVALID; }
+    if ((rc = ensure_staging(e, 0))) return rc;
+    const int C = e->n_classes;
+    for (int b0 = 0; b0 < batch; b0 += e->max_batch) {
+        const int nb = std::min(e->max_batch, batch - b0);
+        HIPCHK(e, hipMemcpyAsync(e->d_spec, spec + (size_t)b0 * APR_SPEC_ELEMS, (size_t)nb * APR_SPEC_ELEMS * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        if ((rc = run_cnn(e, e->d_spec, nb, trust, empty_class, e->d_logits, e->d_probs, e->d_label, e->d_match))) return rc;
+        if (probs) HIPCHK(e, hipMemcpyAsync(probs + (size_t)b0 * C, e->d_probs, (size_t)nb * C * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (label) HIPCHK(e, hipMemcpyAsync(label + b0, e->d_label, (size_t)nb * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        if (match) HIPCHK(e, hipMemcpyAsync(match + b0, e->d_match, (size_t)nb, hipMemcpyDeviceToHost, e->stream));
+        if (logits) HIPCHK(e, hipMemcpyAsync(logits + (size_t)b0 * C, e->d_logits, (size_t)nb * C * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return APR_OK;
+}
+
 int apr_score_device(apr_engine *e, const uint8_t *d_pcm, size_t total_bytes, size_t n_windows, size_t stride_bytes, double trust,
                      int empty_class, double *d_probs, int32_t *d_label, uint8_t *d_match, float *d_logits)
 {

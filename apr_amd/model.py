@@ -151,6 +151,23 @@ class Engine:
         self._chk(self._lib.apr_infer(self._h, s.ctypes.data, s.shape[0], out.ctypes.data))
         return out
 
+    def classify(self, spec, trust: float = 0.5, empty_class: int = -1):
+        """Infer + decision on prepared spectrograms -> dict(probs, label, match, logits)."""
+        s = np.ascontiguousarray(spec, np.float32).reshape(-1, Nmels, SpectrogramFrames)
+        n = s.shape[0]
+        probs = np.empty((n, self.num_classes), np.float64)
+        logits = np.empty((n, self.num_classes), np.float32)
+        label = np.empty(n, np.int32)
+        match = np.empty(n, np.uint8)
+        self._chk(self._lib.apr_classify(self._h, s.ctypes.data, n, trust, empty_class, probs.ctypes.data,
+                                         label.ctypes.data, match.ctypes.data, logits.ctypes.data))
+        return dict(probs=probs, label=label, match=match, logits=logits)
+
+    def classify_device(self, d_spec, batch: int, trust: float, empty_class: int, d_probs=None, d_label=None,
+                        d_match=None, d_logits=None) -> None:
+        self._chk(self._lib.apr_classify_device(self._h, _addr(d_spec), batch, trust, empty_class, _addr(d_probs),
+                                                _addr(d_label), _addr(d_match), _addr(d_logits)))
+
     def score(self, pcm, n_windows: Optional[int] = None, stride: int = BytesPerSecond, trust: float = 0.5,
               empty_class: int = -1):
         """Fused sweep over one PCM buffer -> dict(probs [n,C] f64, label [n] i32, match [n] u8)."""

@@ -114,3 +114,104 @@ def gather_scores(probs, label, counts: Sequence[int], dist=None, dst: int = 0):
     out = out.view(world, cap, C + 1)
     return ([out[r, : counts[r], :C] for r in range(world)],
             [out[r, : counts[r], C].to(torch.int32) for r in range(world)])
+
+
+# ----------------------------------------------------------------------------------------------
+# tagged clips on disk: tags/<tag>/<file>:<n>.dat = 2 s of raw s16le 48 kHz
+# (src/review/action.go:190-224 writes them, ai/model.py:155-160 / ai/train.py:128-135 read them)
+# ----------------------------------------------------------------------------------------------
+def dat_name(recording: str, frame: int) -> str:
+    """src/review/action.go:202-204: '<recording file name>:<first second>.dat'."""
+    import os
+    return f"{os.path.basename(recording)}:{frame}.dat"
+
+
+def write_dat(path: str, pcm_2s) -> None:
+    b = np.ascontiguousarray(pcm_2s).view(np.uint8).reshape(-1)
+    if b.size != SAMPLE_SIZE:
+        raise ValueError(f"a tagged clip is {SAMPLE_SIZE} bytes (two 1-s segments), got {b.size}")
+    b.tofile(path)
+
+
+def read_dat(path: str) -> np.ndarray:
+    """Raw bytes of a tagged clip (any length: Prepare pads / truncates, model.go:87-96)."""
+    return np.fromfile(path, np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------
+# multi-model fan-out: one spectrogram, every configured model
+# (src/daemon/daemon.go:93-99,132-136 and ai/inspect.py:133-159)
+# ----------------------------------------------------------------------------------------------
+class MultiModelSweep:
+    """``models`` = {name: (Engine, labels)}; ``frontend`` = a front-end Engine.  The spectrograms
+    are computed ONCE per recording and handed to every model, as the reference does."""
+
+    def __init__(self, frontend, models: Dict[str, tuple], trust: float = 0.5):
+        self.frontend = frontend
+        self.models = models
+        self.trust = trust
+
+    def score_recording(self, pcm, stride: int = BYTES_PER_SECOND) -> Dict[str, dict]:
+        b = np.ascontiguousarray(pcm).view(np.uint8).reshape(-1)
+        n = windows_in(b.size, stride)
+        spec = self.frontend.prepare_batch(b, n, stride)
+        out = {}
+        for name, (eng, labels) in self.models.items():
+            empty = labels.index("empty") if "empty" in labels else -1
+            out[name] = eng.classify(spec, self.trust, empty)
+        return out
+
+    def inspect_lines(self, file_name: str, pcm) -> List[str]:
+        """What ``python -m ai.inspect -i <file>`` prints (ai/inspect.py:73-84): window-major,
+        model-minor, 1-based window index, 'empty' skipped, no threshold."""
+        res = self.score_recording(pcm)
+        n = len(next(iter(res.values()))["label"]) if res else 0
+        lines = []
+        for k in range(n):
+            for name, (_, labels) in self.models.items():
+                lab = int(res[name]["label"][k])
+                if lab < 0 or labels[lab] == "empty":
+                    continue
+                lines.append(f"Matched {name}/{labels[lab]} in {file_name} @{k + 1} sec")
+        return lines
+
+    def daemon_lines(self, pcm) -> List[str]:
+        """The [INFO] lines the monitor daemon would log for this stream (daemon.go:203-204)."""
+        res = self.score_recording(pcm)
+        lines = []
+        n = len(next(iter(res.values()))["label"]) if res else 0
+        for k in range(n):
+            for name, (_, labels) in self.models.items():
+                r = res[name]
+                if r["match"][k]:
+                    lab = int(r["label"][k])
+                    lines.append(daemon_match_line(name, labels[lab], float(r["probs"][k, lab])))
+        return lines
+
+
+# ----------------------------------------------------------------------------------------------
+# live mode (BASELINE config 4): many concurrent streams, one 1-s segment each per tick
+# (src/daemon/daemon.go:104-125: window = previous segment || new segment)
+# ----------------------------------------------------------------------------------------------
+class StreamScorer:
+    """Keeps the previous 1-s segment of every stream; ``tick(segments)`` scores the n_streams
+    windows [previous || new] in one GPU pass.  The first tick only primes the buffers
+    (daemon.go:115-119) and returns None."""
+
+    def __init__(self, engine, n_streams: int, trust: float = 0.5, empty_class: int = -1):
+        self.engine = engine
+        self.n = n_streams
+        self.trust = trust
+        self.empty = empty_class
+        self.buf = np.zeros((n_streams, SAMPLE_SIZE), np.uint8)
+        self.primed = False
+
+    def tick(self, segments) -> Optional[dict]:
+        seg = np.ascontiguousarray(segments).view(np.uint8).reshape(self.n, BYTES_PER_SECOND)
+        if not self.primed:
+            self.buf[:, BYTES_PER_SECOND:] = seg
+            self.primed = True
+            return None
+        self.buf[:, :BYTES_PER_SECOND] = self.buf[:, BYTES_PER_SECOND:]
+        self.buf[:, BYTES_PER_SECOND:] = seg
+        return self.engine.score(self.buf, self.n, SAMPLE_SIZE, self.trust, self.empty)

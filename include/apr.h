@@ -151,6 +151,21 @@ int apr_prepare_batch_device(apr_engine *e, int flavour, const uint8_t *d_pcm, s
 /* Device-resident CNN: d_spec [batch][128][188] -> d_logits [batch][C].  Asynchronous. */
 int apr_infer_device(apr_engine *e, const float *d_spec, int batch, float *d_logits);
 
+/*
+ * Infer + decision for spectrograms that are already prepared: the CNN, the f64 softmax
+ * (src/model/model.go:211-228) and the daemon's rule (src/daemon/daemon.go:189-207) for `batch`
+ * spectrograms [batch][128][188].  This is the per-model half of the daemon's fan-out
+ * (src/daemon/daemon.go:132-136: ONE prepared tensor is handed to every configured model;
+ * ai/inspect.py:133-159 loops the models over one spectrogram the same way): prepare once with
+ * apr_prepare_batch[_device], then call this on each model's engine.
+ * apr_classify takes host pointers and is synchronous; apr_classify_device takes GPU pointers and
+ * is asynchronous on the engine's stream.  Any output may be NULL.
+ */
+int apr_classify(apr_engine *e, const float *spec, int batch, double trust, int empty_class, double *probs,
+                 int32_t *label, uint8_t *match, float *logits);
+int apr_classify_device(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class,
+                        double *d_probs, int32_t *d_label, uint8_t *d_match, float *d_logits);
+
 /* Block until all work queued on this engine's stream has finished. */
 int apr_sync(apr_engine *e);
 

@@ -175,3 +175,61 @@ def test_errors_are_codes_not_crashes(fe):
         model.Engine(None, 999, 8)
     out = fe.prepare_batch(np.zeros(10, np.uint8), 0)
     assert out.shape == (0, 128, 188)
+
+
+def test_multi_model_fanout_shares_one_spectrogram(he_weights, fe):
+    from apr_amd import sweep
+    w2 = W.random_init(3, 5, "he")
+    ea = model.Engine(W.pack_blob(he_weights, 4), 0, 16)
+    eb = model.Engine(W.write_onnx(w2, 3), 0, 16)
+    labels_b = ["empty", "horn", "siren"]
+    mm = sweep.MultiModelSweep(fe, {"dogs": (ea, LABELS), "traffic": (eb, labels_b)}, trust=0.4)
+    pcm = model.synth_pcm(9, 2, 8)
+    res = mm.score_recording(pcm)
+    one_a = ea.score(pcm, trust=0.4, empty_class=2)
+    one_b = eb.score(pcm, trust=0.4, empty_class=0)
+    assert np.array_equal(res["dogs"]["label"], one_a["label"]) and np.array_equal(res["dogs"]["probs"], one_a["probs"])
+    assert np.array_equal(res["traffic"]["match"], one_b["match"]) and np.array_equal(res["traffic"]["probs"], one_b["probs"])
+    o = oracle.score(w2, 3, pcm, 7, trust=0.4, empty_class=0)
+    assert np.abs(res["traffic"]["probs"] - o["probs"]).max() <= 1e-4
+    lines = mm.inspect_lines("rec.mkv", pcm)
+    want = []
+    for k in range(7):
+        for name, labs, r in (("dogs", LABELS, one_a), ("traffic", labels_b, one_b)):
+            lab = labs[int(r["label"][k])]
+            if lab != "empty":
+                want.append(f"Matched {name}/{lab} in rec.mkv @{k + 1} sec")
+    assert lines == want
+    assert all(l.startswith("[INFO]\t SCANNER ") for l in mm.daemon_lines(pcm))
+    ea.close(); eb.close()
+
+
+def test_stream_scorer_equals_batch_sweep(eng):
+    from apr_amd import sweep
+    n_streams, secs = 5, 6
+    pcm = [model.synth_pcm(11, s, secs).view(np.uint8).reshape(secs, 96000) for s in range(n_streams)]
+    sc = sweep.StreamScorer(eng, n_streams, trust=0.5, empty_class=2)
+    assert sc.tick(np.stack([p[0] for p in pcm])) is None          # first segment only primes (daemon.go:115-119)
+    got = [sc.tick(np.stack([p[t] for p in pcm])) for t in range(1, secs)]
+    for s in range(n_streams):
+        ref = eng.score(pcm[s].reshape(-1), trust=0.5, empty_class=2)
+        for t in range(secs - 1):
+            assert got[t]["label"][s] == ref["label"][t]
+            assert np.array_equal(got[t]["probs"][s], ref["probs"][t])
+
+
+def test_dat_clip_round_trip_and_librosa_batch(fe, clips, tmp_path):
+    from apr_amd import sweep
+    name = sweep.dat_name("/ws/recordings/2026-01-01.mkv", 17)
+    assert name == "2026-01-01.mkv:17.dat"
+    sweep.write_dat(str(tmp_path / name), clips["test_combo"])
+    back = sweep.read_dat(str(tmp_path / name))
+    assert np.array_equal(back, clips["test_combo"])
+    with pytest.raises(ValueError):
+        sweep.write_dat(str(tmp_path / "x.dat"), clips["test_combo"][:100])
+    # BASELINE config 5 shape: packed .dat clips -> [n,128,188] with the librosa front end
+    packed = np.concatenate([clips[c] for c in ("test_empty", "test_smalldog", "test_bigdog", "test_combo")])
+    got = fe.prepare_batch(packed, 4, stride=192000, flavour=FLAVOUR_LIBROSA)
+    want = oracle.prepare_librosa_batch(packed, 4)
+    assert np.abs(got - want).max() <= 5e-5
+    assert np.array_equal(got[2], model.audio_to_spectrogram(clips["test_bigdog"].tobytes())[0])
