@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Side measurements for BASELINE configs 4 and 5 on one GPU (bench.py stays the headline).
+
+  config 4  live mode: 256 concurrent streams, one 1-s segment each per tick, window = previous
+            segment || new segment (src/daemon/daemon.go:104-125); p50/p99 from segment arrival
+            (host memory) to labels (host memory), and the sustained windows/s.
+  config 5  training-set preprocessing: 10 000 tagged .dat clips (192 000 B each) -> librosa-flavour
+            log-mel [10000,1,128,188] (ai/train.py:36-52), clips already in HBM.
+Prints one JSON line per config.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--streams", type=int, default=256)
+    ap.add_argument("--ticks", type=int, default=40)
+    ap.add_argument("--clips", type=int, default=10000)
+    args = ap.parse_args()
+    import torch
+    from apr_amd import model, sweep, weights as W
+    from apr_amd._capi import FLAVOUR_LIBROSA
+    dev = torch.device("cuda", 0)
+
+    # ---------------- config 4 ----------------
+    C = 4
+    eng = model.Engine(W.pack_blob(W.random_init(C, 0, "he"), C), 0, args.streams)
+    secs = 8
+    src = np.stack([model.synth_pcm(4, s, secs).view(np.uint8).reshape(secs, 96000) for s in range(args.streams)])
+    sc = sweep.StreamScorer(eng, args.streams, trust=0.5, empty_class=2)
+    sc.tick(src[:, 0])
+    lat = []
+    for t in range(args.ticks):
+        seg = src[:, 1 + t % (secs - 1)]
+        t0 = time.perf_counter()
+        sc.tick(seg)
+        lat.append(1e3 * (time.perf_counter() - t0))
+    lat = np.array(lat[3:])
+    print(json.dumps({"config": 4, "streams": args.streams, "ticks": int(lat.size),
+                      "latency_ms_p50": float(np.percentile(lat, 50)), "latency_ms_p99": float(np.percentile(lat, 99)),
+                      "latency_ms_max": float(lat.max()), "real_time_budget_ms": 1000.0,
+                      "sustained_windows_per_s": float(args.streams / (np.mean(lat) * 1e-3)),
+                      "note": "host->device copy of 256 x 192000 B, fused score, device->host of labels inside each tick"}),
+          flush=True)
+    eng.close()
+
+    # ---------------- config 5 ----------------
+    fe = model.Engine(None, 0, 1024)
+    uniq = 500
+    clips = np.concatenate([model.synth_pcm(5, i, 2) for i in range(uniq)]).view(np.uint8)
+    reps = (args.clips + uniq - 1) // uniq
+    d_pcm = torch.from_numpy(np.tile(clips, reps)[: args.clips * 192000]).to(dev)
+    d_out = torch.empty((args.clips, 128, 188), dtype=torch.float32, device=dev)
+    fe.prepare_batch_device(d_pcm, d_pcm.numel(), args.clips, 192000, d_out, FLAVOUR_LIBROSA)
+    fe.sync()
+    t0 = time.perf_counter()
+    n_rep = 5
+    for _ in range(n_rep):
+        fe.prepare_batch_device(d_pcm, d_pcm.numel(), args.clips, 192000, d_out, FLAVOUR_LIBROSA)
+    fe.sync()
+    dt = (time.perf_counter() - t0) / n_rep
+    in_b, out_b = args.clips * 192000, args.clips * 128 * 188 * 4
+    print(json.dumps({"config": 5, "clips": args.clips, "ms": 1e3 * dt, "clips_per_s": args.clips / dt,
+                      "algorithmic_GBps": (in_b + out_b) / dt / 1e9, "flavour": "librosa",
+                      "checksum": float(d_out[:uniq].double().sum().item())}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
