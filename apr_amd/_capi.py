@@ -12,7 +12,7 @@ APR_OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_MODEL, ERR_NOMEM, ERR_NOMODEL = -1, -2, -3, -4, -5
 FLAVOUR_GO, FLAVOUR_LIBROSA = 0, 1
 WARN_UNDERFLOW, WARN_OVERFLOW = 1, 2
-PROF_SLOTS = 16
+PROF_SLOTS = 48
 
 # every symbol include/apr.h declares (tests check the library exports all of them)
 SYMBOLS = (

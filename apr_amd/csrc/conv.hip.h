@@ -32,9 +32,6 @@ namespace apr {
 #ifndef APR_EXP_BDMA
 #define APR_EXP_BDMA 1
 #endif
-#ifndef APR_EXP_FINE
-#define APR_EXP_FINE 0
-#endif
 #ifndef APR_EXP_BK
 #define APR_EXP_BK 16
 #endif
@@ -111,9 +108,12 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rs, unsigned voff, int soff, 
 //   4x ds_write_b32 staging and the one-dword-per-lane MFMA operand reads), B tile
 //   [k][n]; double buffered, one barrier per K step; next tile's global loads are
 //   issued before the MFMAs of the current one.
-//   Requires Cin % 32 == 0 and Cout % BN == 0 (checked on the host).
+//   Requires Cin % 16 == 0 and Cout % BN == 0 (checked on the host).
+//   MODE 1 runs the same pipeline as a batch of plain GEMMs (the Winograd domain):
+//   blockIdx.y = transform position pos, out[pos][M][Cout] = in[pos][M][Cin] x wt[pos][Cin][Cout],
+//   one "tap", no padding, raw stores (bias/ReLU belong to the output transform).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int STRIDE>
+template <int BM, int BN, int STRIDE, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restrict__ in,
                                                             const float *__restrict__ wt,
                                                             const float *__restrict__ bias,
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     constexpr int BPASS = BK / BROWS;
     constexpr int LDA = BM + 1;
     constexpr int NK = BK / 2;           // k-pairs (one v_mfma_f32_32x32x2 each) per K step
-    constexpr int ST0 = APR_EXP_ST0 + (APR_EXP_FINE ? 1 : 0);     // first k-pair that stages a piece of the next tile
+    constexpr int ST0 = APR_EXP_ST0;     // first k-pair that stages a piece of the next tile
     static_assert(TM >= 1 && TN >= 1 && BPASS >= 1, "tile too small");
     static_assert(ST0 + AROWS <= NK && ST0 + BPASS <= NK, "staging does not fit in the K step");
 
@@ -155,11 +155,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     //      load instead of 64-bit pointer arithmetic.  Zero padding and rows past M use an
     //      out-of-range offset: the buffer unit returns 0 for those lanes.
     constexpr unsigned OOB = 0x80000000u;            // >= num_records of the A descriptor
+    constexpr int TAPS = MODE == 0 ? 9 : 1;
     const int p0 = bm * BM;                          // first output pixel of this block (< M)
-    const long long b0 = (p0 / Wo) / Ho;             // its window
+    const long long b0 = MODE == 0 ? (p0 / Wo) / Ho : 0;   // its window
+    if (MODE == 1) {                                 // batched GEMM: this block's problem
+        in += (size_t)blockIdx.y * M * Cin;
+        wt += (size_t)blockIdx.y * Cin * Cout;
+        out += (size_t)blockIdx.y * M * Cout;
+    }
     // descriptor base = one row and one column before window b0's image, so every valid
-    // tap has a non-negative offset (the base itself may lie before `in`; never dereferenced)
-    const float *abase = in + ((b0 * H - 1) * W - 1) * (long long)Cin;
+    // tap has a non-negative offset (the base itself may lie before `in`; never dereferenced);
+    // MODE 1: the block's first row
+    const float *abase = MODE == 0 ? in + ((b0 * H - 1) * W - 1) * (long long)Cin : in + (long long)p0 * Cin;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x40000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(wt + (size_t)bn * BN), 0, 0x7FFFFFFF, 0x00020000);
 
@@ -170,7 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         const int p = p0 + ar0 + AR * i;             // M < 2^31 (host-checked)
         rowmask[i] = 0;
         rowoff[i] = OOB;
-        if (p < M) {
+        if (MODE == 1) {
+            if (p < M) { rowoff[i] = 4u * (unsigned)((ar0 + AR * i) * Cin + ac * 4); rowmask[i] = 1u; }
+        } else if (p < M) {
             const int ow = p % Wo;
             const int t = p / Wo;
             const int oh = t % Ho;
@@ -202,14 +211,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const unsigned bs_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(&Bs[0][0] + wave * (64 / BCH) * BN));
 
     const int cchunks = Cin / BK;
-    const int KT = 9 * cchunks;
+    const int KT = TAPS * cchunks;
 
     f32x4 ra[AROWS], rb[BPASS];
 #define APR_LOAD_TILES(KT_)                                                                              \
     {                                                                                                    \
         const int tap_ = (KT_) / cchunks;                                                                \
         const int c0_ = ((KT_) - tap_ * cchunks) * BK;                                                   \
-        const int soffA_ = 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_);                              \
+        const int soffA_ = MODE == 0 ? 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_) : 4 * c0_;        \
         const int soffB_ = 4 * (KT_) * BK * Cout;                                                        \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
@@ -265,65 +274,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     // ST0 on (that buffer was released by the barrier that ended the previous step).  hipcc
     // would otherwise sink every ds_read next to its MFMA (lgkmcnt(0) before each group), so
     // memory instructions and MFMAs are fenced per k-pair; only VALU/SALU may move (mask 0x6).
-#if APR_EXP_FINE
-    // Fine interleave: every MFMA is followed by one small piece of the other work (a fragment
-    // read, two loads, two LDS-DMA issues or one staged row), fenced so that it stays there: an
-    // MFMA occupies the matrix pipe for 64 cycles but the issue port only briefly, so a handful
-    // of other instructions behind each MFMA are free, while a long run of them is not.
-#define APR_MFMA(KK_, N_)                                                                                \
-    acc[(N_) / TN][(N_) % TN] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(KK_) & 1][(N_) / TN], bf[(KK_) & 1][(N_) % TN], acc[(N_) / TN][(N_) % TN], 0, 0, 0);
-#define APR_PIECE_RA(KK_)                                                                                \
-    if ((KK_) + 1 < NK) { _Pragma("unroll") for (int i = 0; i < TM; i++) af[((KK_) + 1) & 1][i] = a[(2 * ((KK_) + 1) + half) * LDA + i * 32]; }
-#define APR_PIECE_RB(KK_)                                                                                \
-    if ((KK_) + 1 < NK) { _Pragma("unroll") for (int j = 0; j < TN; j++) bf[((KK_) + 1) & 1][j] = b[(2 * ((KK_) + 1) + half) * BN + j * 32]; }
-#define APR_PIECE_STAGE(KK_, HAS_NEXT)                                                                   \
-    if (APR_EXP_STAGE && HAS_NEXT) {                                                                     \
-        if ((KK_) == 1) {                                                                                \
-            const int tap_ = (kt + 1) / cchunks;                                                         \
-            const int c0_ = ((kt + 1) - tap_ * cchunks) * BK;                                            \
-            soffA_n = 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_);                                   \
-            tap_n = tap_;                                                                                \
-        }                                                                                                \
-        if ((KK_) == 1 || (KK_) == 2) {                                                                  \
-            _Pragma("unroll") for (int i = ((KK_) == 1 ? 0 : (AROWS + 1) / 2); i < ((KK_) == 1 ? (AROWS + 1) / 2 : AROWS); i++) \
-            {                                                                                            \
-                const unsigned vo_ = ((rowmask[i] >> tap_n) & 1u) ? rowoff[i] : OOB;                     \
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo_, soffA_n, 0)); \
-            }                                                                                            \
-        }                                                                                                \
-        if ((KK_) == 3 || (KK_) == 4) {                                                                  \
-            const int soffB_ = 4 * (kt + 1) * BK * Cout;                                                 \
-            const unsigned lds_ = bs_lds + 4u * (unsigned)((cur ^ 1) * BK * BN);                         \
-            _Pragma("unroll") for (int i = ((KK_) == 3 ? 0 : (BPASS + 1) / 2); i < ((KK_) == 3 ? (BPASS + 1) / 2 : BPASS); i++) \
-                lds_dma_b128(rsBv, boff[i], soffB_, lds_ + 4u * (unsigned)(BROWS * i * BN));             \
-        }                                                                                                \
-        if ((KK_) >= ST0 && (KK_) < ST0 + AROWS) APR_STORE_A(cur ^ 1, (KK_) - ST0)                       \
-    }
-#define APR_KSTEP(HAS_NEXT)                                                                              \
-    {                                                                                                    \
-        const float *a = As[cur] + wm * WM + li;                                                         \
-        const float *b = Bs[cur] + wn * WN + li;                                                         \
-        float af[2][TM], bf[2][TN];                                                                      \
-        int soffA_n = 0, tap_n = 0;                                                                      \
-        _Pragma("unroll") for (int i = 0; i < TM; i++) af[0][i] = a[half * LDA + i * 32];                \
-        _Pragma("unroll") for (int j = 0; j < TN; j++) bf[0][j] = b[half * BN + j * 32];                 \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        _Pragma("unroll") for (int kk = 0; kk < NK; kk++)                                                \
-        {                                                                                                \
-            _Pragma("unroll") for (int n = 0; n < TM * TN; n++)                                          \
-            {                                                                                            \
-                APR_MFMA(kk, n)                                                                          \
-                if (n == 0) APR_PIECE_RA(kk)                                                             \
-                if (n == (TM * TN > 1 ? 1 : 0)) APR_PIECE_RB(kk)                                         \
-                if (n == (TM * TN > 2 ? 2 : TM * TN - 1)) APR_PIECE_STAGE(kk, HAS_NEXT)                  \
-                __builtin_amdgcn_sched_barrier(0);                                                       \
-            }                                                                                            \
-        }                                                                                                \
-        if (APR_EXP_BDMA && HAS_NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
-        if (APR_EXP_SYNC) __syncthreads();                                                               \
-        cur ^= 1;                                                                                        \
-    }
-#else
 #define APR_KSTEP(HAS_NEXT)                                                                              \
     {                                                                                                    \
         const float *a = As[cur] + wm * WM + li;                                                         \
@@ -357,19 +307,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         cur ^= 1;                                                                                        \
     }
 
-#endif
-
     int cur = 0;
     int kt = 0;
     for (; kt < KT - 1; kt++) APR_KSTEP(true)
     APR_KSTEP(false)
 #undef APR_KSTEP
-#if APR_EXP_FINE
-#undef APR_MFMA
-#undef APR_PIECE_RA
-#undef APR_PIECE_RB
-#undef APR_PIECE_STAGE
-#endif
 
     // ---- epilogue: bias + ReLU, NHWC store.  D[row][col]: col = lane&31,
     //      row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
@@ -377,19 +319,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = bn * BN + wn * WN + j * 32 + li;
-        const float bv = bias[n];
+        const float bv = MODE == 0 ? bias[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int prow = p0 + wm * WM + i * 32 + 4 * half;
             float *o = out + (long long)prow * Cout + n;
             if (full) {
 #pragma unroll
-                for (int e = 0; e < 16; e++) o[(long long)((e & 3) + 8 * (e >> 2)) * Cout] = fmaxf(acc[i][j][e] + bv, 0.0f);
+                for (int e = 0; e < 16; e++) {
+                    const float v = acc[i][j][e] + bv;
+                    o[(long long)((e & 3) + 8 * (e >> 2)) * Cout] = MODE == 0 ? fmaxf(v, 0.0f) : v;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int p = prow + (e & 3) + 8 * (e >> 2);
-                    if (p < M) out[(long long)p * Cout + n] = fmaxf(acc[i][j][e] + bv, 0.0f);
+                    const float v = acc[i][j][e] + bv;
+                    if (p < M) out[(long long)p * Cout + n] = MODE == 0 ? fmaxf(v, 0.0f) : v;
                 }
             }
         }

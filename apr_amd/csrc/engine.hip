@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "conv.hip.h"
 #include "frontend.hip.h"
 #include "model_parse.h"
+#include "wino.hip.h"
 
 using namespace apr;
 
@@ -28,6 +30,12 @@ struct Layer {
     float *d_w = nullptr;   // [9][cin][cout]
     float *d_b = nullptr;   // [cout]
     int bn_tile = 0, bm_tile = 128;
+    // Winograd F(2x2,3x3) path (stride-1 layers with enough channels to amortise the transforms)
+    int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3)
+    float *d_u = nullptr;   // [16][cin][cout] = G g G^T
+    int th = 0, tw = 0;     // 2x2-output tiles per window
+    int wbm_tile = 128;
+    int slot = -1, slot_in = -1, slot_out = -1;   // profile slots of its kernels
 };
 
 struct ProfPair {
@@ -55,7 +63,7 @@ struct apr_engine {
     std::vector<Layer> layers;
     float *d_act[2] = {nullptr, nullptr};
     float *d_wfc = nullptr, *d_bfc = nullptr;
-    float *d_zeros = nullptr;     // 256 B of 0.0f: source of the convolutions' zero padding
+    float *d_V = nullptr, *d_M = nullptr;   // Winograd-domain activations [16][T][Cin] / [16][T][Cout]
 
     // staging for the host-pointer entry points
     uint8_t *d_pcm = nullptr;
@@ -69,6 +77,7 @@ struct apr_engine {
     bool prof_on = false;
     apr_profile_slot slots[APR_PROF_SLOTS];
     int n_slots = 0;
+    int head_slot = -1;
     std::vector<ProfPair> pending;
     std::vector<hipEvent_t> free_events;
 };
@@ -219,10 +228,15 @@ void add_slot(apr_engine *e, const char *name, int layer)
 int build_cnn(apr_engine *e, const ParsedModel &pm)
 {
     if (pm.n_classes < 1 || pm.n_classes > APR_MAX_CLASSES) { e->err = "class count out of range"; return APR_ERR_MODEL; }
-    if ((int)pm.convs.size() + 3 > APR_PROF_SLOTS) { e->err = "too many conv layers"; return APR_ERR_MODEL; }
+    if (3 * (int)pm.convs.size() + 3 > APR_PROF_SLOTS) { e->err = "too many conv layers"; return APR_ERR_MODEL; }
     if (pm.features > 1024 || pm.features % 4) { e->err = "unsupported classifier width"; return APR_ERR_MODEL; }
     int h = kNmels, w = kSpecFrames, rc;
-    size_t act_max = 0;
+    size_t act_max = 0, v_max = 0, m_max = 0;
+    // APR_WINOGRAD=0 disables the Winograd path; APR_WINO_MIN_CIN moves its channel threshold
+    const char *wenv = getenv("APR_WINOGRAD");
+    const bool wino_on = !(wenv && wenv[0] == '0');
+    const char *cenv = getenv("APR_WINO_MIN_CIN");
+    const int wino_min_cin = cenv ? atoi(cenv) : 128;
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
         Layer L;
@@ -246,6 +260,31 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             for (int c = 0; c < cv.cin; c++)
                 for (int t = 0; t < 9; t++) wt[((size_t)t * cv.cin + c) * cv.cout + o] = cv.w[((size_t)o * cv.cin + c) * 9 + t];
         if ((rc = dev_upload(e, &L.d_w, wt)) || (rc = dev_upload(e, &L.d_b, cv.b))) return rc;
+        if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= wino_min_cin && cv.cout % 128 == 0) {
+            // U[pos = 4 i + j][cin][cout] = (G g G^T)[i][j], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in f64
+            static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            std::vector<float> u((size_t)16 * cv.cin * cv.cout);
+            for (int o = 0; o < cv.cout; o++)
+                for (int c = 0; c < cv.cin; c++) {
+                    const float *g = &cv.w[((size_t)o * cv.cin + c) * 9];
+                    double t[4][3];
+                    for (int i = 0; i < 4; i++)
+                        for (int k = 0; k < 3; k++) t[i][k] = G[i][0] * g[k] + G[i][1] * g[3 + k] + G[i][2] * g[6 + k];
+                    for (int i = 0; i < 4; i++)
+                        for (int j = 0; j < 4; j++) {
+                            const double v = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                            u[((size_t)(4 * i + j) * cv.cin + c) * cv.cout + o] = (float)v;
+                        }
+                }
+            if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+            L.wino = 2;
+            L.th = (L.hout + 1) / 2;
+            L.tw = (L.wout + 1) / 2;
+            const long long t_full = (long long)e->max_batch * L.th * L.tw;
+            L.wbm_tile = ((t_full + 127) / 128) * (cv.cout / 128) * 16 < 1024 ? 64 : 128;
+            v_max = std::max(v_max, (size_t)16 * L.th * L.tw * cv.cin);
+            m_max = std::max(m_max, (size_t)16 * L.th * L.tw * cv.cout);
+        }
         act_max = std::max(act_max, (size_t)L.cout * L.hout * L.wout);
         h = L.hout; w = L.wout;
         e->layers.push_back(L);
@@ -256,7 +295,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     if ((rc = dev_upload(e, &e->d_wfc, pm.fc_w)) || (rc = dev_upload(e, &e->d_bfc, pm.fc_b))) return rc;
     for (int i = 0; i < 2; i++)
         if ((rc = dev_alloc(e, &e->d_act[i], act_max * (size_t)e->max_batch))) return rc;
-    if ((rc = dev_upload(e, &e->d_zeros, std::vector<float>(64, 0.0f)))) return rc;
+    if (v_max && ((rc = dev_alloc(e, &e->d_V, v_max * (size_t)e->max_batch)) || (rc = dev_alloc(e, &e->d_M, m_max * (size_t)e->max_batch)))) return rc;
     return APR_OK;
 }
 
@@ -335,6 +374,15 @@ void launch_igemm(apr_engine *e, const Layer &L, const float *in, float *out, lo
                        L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n);
 }
 
+template <int BM>
+void launch_wino_gemm(apr_engine *e, const Layer &L, long long T)
+{
+    const int tiles_n = L.cout / 128;
+    const long long tiles_m = (T + BM - 1) / BM;
+    hipLaunchKernelGGL((conv3x3_igemm_f32<BM, 128, 1, 1>), dim3((unsigned)(tiles_m * tiles_n), 16), dim3(256), 0, e->stream, e->d_V,
+                       L.d_u, L.d_b, e->d_M, 1, 1, L.cin, 1, 1, L.cout, (int)T, tiles_n);
+}
+
 int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class, float *d_logits, double *d_probs,
             int32_t *d_label, uint8_t *d_match)
 {
@@ -346,7 +394,28 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
         const long long M = (long long)batch * L.hout * L.wout;
         const double flops = 2.0 * (double)M * L.cout * 9.0 * L.cin;
         const double bytes = 4.0 * ((double)batch * L.hin * L.win * L.cin + (double)M * L.cout + 9.0 * L.cin * L.cout);
-        ProfScope ps(e, 2 + (int)l, flops, bytes);
+        if (L.wino) {
+            const long long T = (long long)batch * L.th * L.tw;
+            const long long nv = T * (L.cin / 4), nm = T * (L.cout / 4);
+            {
+                ProfScope ps(e, L.slot_in, 0.0, 4.0 * ((double)batch * L.hin * L.win * L.cin + 16.0 * T * L.cin));
+                hipLaunchKernelGGL(wino_input_f2, dim3((unsigned)std::min<long long>((nv + 255) / 256, 65536)), dim3(256), 0, e->stream, in,
+                                   e->d_V, L.hin, L.win, L.cin, L.th, L.tw, T);
+            }
+            {
+                ProfScope ps(e, L.slot, 2.0 * 16.0 * (double)T * L.cin * L.cout, 4.0 * 16.0 * ((double)T * (L.cin + L.cout) + (double)L.cin * L.cout));
+                if (L.wbm_tile == 64) launch_wino_gemm<64>(e, L, T);
+                else launch_wino_gemm<128>(e, L, T);
+            }
+            {
+                ProfScope ps(e, L.slot_out, 0.0, 4.0 * (16.0 * T * L.cout + (double)M * L.cout));
+                hipLaunchKernelGGL(wino_output_f2, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
+                                   e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
+            }
+            in = out;
+            continue;
+        }
+        ProfScope ps(e, L.slot, flops, bytes);
         if (l == 0) {
             const long long blocks = std::min<long long>((M + 31) / 32, 256 * 32);
             hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, in, L.d_w, L.d_b, out, L.hin,
@@ -366,7 +435,7 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
         in = out;
     }
     {
-        ProfScope ps(e, 2 + (int)e->layers.size(), 2.0 * batch * e->features * e->n_classes,
+        ProfScope ps(e, e->head_slot, 2.0 * batch * e->features * e->n_classes,
                      4.0 * batch * e->pool_pixels * e->features);
         hipLaunchKernelGGL(head_kernel, dim3(batch), dim3(256), 0, e->stream, in, e->pool_pixels, e->features, e->d_wfc,
                            e->d_bfc, e->n_classes, trust, empty_class, d_logits, d_probs, d_label, d_match);
@@ -461,12 +530,22 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
     if (!rc && has_model) rc = build_cnn(e, pm);
     if (!rc && has_model) {
         for (size_t l = 0; l < e->layers.size(); l++) {
-            const Layer &L = e->layers[l];
+            Layer &L = e->layers[l];
             char nm[48];
-            if (l == 0) snprintf(nm, sizeof nm, "conv1_kernel");
-            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d>", L.bm_tile, L.bn_tile, L.stride);
+            if (L.wino) {
+                L.slot_in = e->n_slots;
+                add_slot(e, "wino_input_f2", (int)l + 1);
+                snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 1>", L.wbm_tile);
+            } else if (l == 0) snprintf(nm, sizeof nm, "conv1_kernel");
+            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d, 0>", L.bm_tile, L.bn_tile, L.stride);
+            L.slot = e->n_slots;
             add_slot(e, nm, (int)l + 1);
+            if (L.wino) {
+                L.slot_out = e->n_slots;
+                add_slot(e, "wino_output_f2", (int)l + 1);
+            }
         }
+        e->head_slot = e->n_slots;
         add_slot(e, "head_kernel", -1);
     }
     if (rc) {

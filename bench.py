@@ -179,7 +179,10 @@ def main() -> int:
                          for s in prof if s["layer"] > 0]
         cnn_flops = sum(s["flops"] for s in prof if s["layer"] > 0)
         cnn_ms = sum(s["ms"] for s in prof if s["layer"] > 0)
-        out["cnn_tflops"] = cnn_flops / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None
+        out["cnn_tflops"] = cnn_flops / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None      # FLOPs actually executed
+        # direct-convolution-equivalent rate (5 171 281 920 FLOP per window); exceeds the
+        # executed rate because the Winograd layers do 2.25x fewer multiplies for the same result
+        out["cnn_effective_tflops"] = (5171281920.0 * plan.n_windows * args.steps) / (cnn_ms * 1e-3) / 1e12 if cnn_ms else None
 
     # ---- per-clip latency: one 2-s window through the host-pointer entry point ----
     if not args.no_extras:

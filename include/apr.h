@@ -177,7 +177,7 @@ void *apr_engine_stream(apr_engine *e);
  * counterpart; measurement hook for bench.py).  While enabled, every kernel
  * launch is bracketed by events; apr_profile_read syncs and accumulates.
  */
-#define APR_PROF_SLOTS 16
+#define APR_PROF_SLOTS 48
 typedef struct apr_profile_slot {
     char     name[48];     /* kernel (family) name as rocprofv3 reports it     */
     int32_t  layer;        /* 1..12 for conv layers, -1 otherwise               */

@@ -233,3 +233,19 @@ def test_dat_clip_round_trip_and_librosa_batch(fe, clips, tmp_path):
     want = oracle.prepare_librosa_batch(packed, 4)
     assert np.abs(got - want).max() <= 5e-5
     assert np.array_equal(got[2], model.audio_to_spectrogram(clips["test_bigdog"].tobytes())[0])
+
+
+def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
+    # default engine: Winograd F(2x2,3x3) on the stride-1 layers with Cin >= 128; APR_WINOGRAD=0: all direct
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
+    monkeypatch.setenv("APR_WINOGRAD", "0")
+    e0 = model.Engine(W.pack_blob(he_weights, 4), 0, 8)
+    monkeypatch.delenv("APR_WINOGRAD")
+    monkeypatch.setenv("APR_WINO_MIN_CIN", "64")        # every stride-1 igemm layer through Winograd
+    e1 = model.Engine(W.pack_blob(he_weights, 4), 0, 8)
+    direct, wino = e0.infer_logits(specs), e1.infer_logits(specs)
+    e0.close(); e1.close()
+    assert np.abs(direct - want).max() <= LOGIT_TOL and np.abs(wino - want).max() <= LOGIT_TOL
+    assert np.abs(direct - wino).max() <= 2e-5
+    assert not np.array_equal(direct, wino)             # the two paths really are different arithmetic
