@@ -18,6 +18,7 @@
 #include "frontend.hip.h"
 #include "model_parse.h"
 #include "wino.hip.h"
+#include "wino_fused.hip.h"
 
 using namespace apr;
 
@@ -32,7 +33,7 @@ struct Layer {
     int bn_tile = 0, bm_tile = 128;
     // Winograd F(2x2,3x3) path (stride-1 layers with enough channels to amortise the transforms)
     int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3)
-    float *d_u = nullptr;   // [16][cin][cout] = G g G^T
+    float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
     int th = 0, tw = 0;     // 2x2-output tiles per window
     int wbm_tile = 128;
     int slot = -1, slot_in = -1, slot_out = -1;   // profile slots of its kernels
@@ -237,6 +238,12 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     const bool wino_on = !(wenv && wenv[0] == '0');
     const char *cenv = getenv("APR_WINO_MIN_CIN");
     const int wino_min_cin = cenv ? atoi(cenv) : 128;
+    // the one-kernel form (wino_fused.hip.h) wins while K = Cin is short; APR_WINO_FUSED=0 turns it
+    // off, APR_WINO_FUSED_MAX_CIN moves its upper channel bound
+    const char *fenv = getenv("APR_WINO_FUSED");
+    const bool fused_on = wino_on && !(fenv && fenv[0] == '0');
+    const char *fcenv = getenv("APR_WINO_FUSED_MAX_CIN");
+    const int fused_max_cin = fcenv ? atoi(fcenv) : 256;
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
         Layer L;
@@ -260,7 +267,14 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             for (int c = 0; c < cv.cin; c++)
                 for (int t = 0; t < 9; t++) wt[((size_t)t * cv.cin + c) * cv.cout + o] = cv.w[((size_t)o * cv.cin + c) * 9 + t];
         if ((rc = dev_upload(e, &L.d_w, wt)) || (rc = dev_upload(e, &L.d_b, cv.b))) return rc;
-        if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= wino_min_cin && cv.cout % 128 == 0) {
+        if (fused_on && l > 0 && cv.stride == 1 && cv.cin % 16 == 0 && cv.cin >= 64 && cv.cin <= fused_max_cin && cv.cout % WF_BN == 0) {
+            std::vector<float> u((size_t)16 * cv.cin * cv.cout);
+            wf_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
+            if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+            L.wino = 3;
+            L.th = (L.hout + 1) / 2;
+            L.tw = (L.wout + 1) / 2;
+        } else if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= wino_min_cin && cv.cout % 128 == 0) {
             // U[pos = 4 i + j][cin][cout] = (G g G^T)[i][j], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in f64
             static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             std::vector<float> u((size_t)16 * cv.cin * cv.cout);
@@ -394,6 +408,16 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
         const long long M = (long long)batch * L.hout * L.wout;
         const double flops = 2.0 * (double)M * L.cout * 9.0 * L.cin;
         const double bytes = 4.0 * ((double)batch * L.hin * L.win * L.cin + (double)M * L.cout + 9.0 * L.cin * L.cout);
+        if (L.wino == 3) {
+            const long long T = (long long)batch * L.th * L.tw;   // < 2^31: max_batch is capped at create
+            const int tiles_n = L.cout / WF_BN;
+            const long long tiles_m = (T + WF_TT - 1) / WF_TT;
+            ProfScope ps(e, L.slot, 2.0 * 16.0 * (double)T * L.cin * L.cout, bytes + 4.0 * 7.0 * L.cin * L.cout);
+            hipLaunchKernelGGL(wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
+                               out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n);
+            in = out;
+            continue;
+        }
         if (L.wino) {
             const long long T = (long long)batch * L.th * L.tw;
             const long long nv = T * (L.cin / 4), nm = T * (L.cout / 4);
@@ -526,13 +550,18 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         e->err = "could not create a stream on the device";
         rc = APR_ERR_DEVICE;
     }
+    if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES) != hipSuccess) {
+        e->err = "could not reserve LDS for wino_fused_f2";
+        rc = APR_ERR_DEVICE;
+    }
     if (!rc) rc = build_frontend(e);
     if (!rc && has_model) rc = build_cnn(e, pm);
     if (!rc && has_model) {
         for (size_t l = 0; l < e->layers.size(); l++) {
             Layer &L = e->layers[l];
             char nm[48];
-            if (L.wino) {
+            if (L.wino == 3) snprintf(nm, sizeof nm, "wino_fused_f2");
+            else if (L.wino) {
                 L.slot_in = e->n_slots;
                 add_slot(e, "wino_input_f2", (int)l + 1);
                 snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 1>", L.wbm_tile);
@@ -540,7 +569,7 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
             else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d, 0>", L.bm_tile, L.bn_tile, L.stride);
             L.slot = e->n_slots;
             add_slot(e, nm, (int)l + 1);
-            if (L.wino) {
+            if (L.wino == 2) {
                 L.slot_out = e->n_slots;
                 add_slot(e, "wino_output_f2", (int)l + 1);
             }

@@ -152,7 +152,8 @@ def main() -> int:
             for k in ("ms", "launches", "flops", "bytes"):
                 a[k] += s[k]
         tot_ms = sum(a["ms"] for a in fam.values())
-        dom_name, dom = max(((k, v) for k, v in fam.items() if "igemm" in k), key=lambda kv: kv[1]["ms"])
+        # dominant MFMA kernel = the igemm instantiation or the fused Winograd kernel with the most GPU time
+        dom_name, dom = max(((k, v) for k, v in fam.items() if "igemm" in k or "wino_fused" in k), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
         # WRITE_SIZE cannot be collected inside this process).  Valid for 1024-window launches only.

@@ -236,16 +236,31 @@ def test_dat_clip_round_trip_and_librosa_batch(fe, clips, tmp_path):
 
 
 def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
-    # default engine: Winograd F(2x2,3x3) on the stride-1 layers with Cin >= 128; APR_WINOGRAD=0: all direct
+    # default engine: Winograd F(2x2,3x3) on the stride-1 layers -- the one-kernel form (wino_fused_f2) up to
+    # Cin 256, transform kernels + batched GEMM above; APR_WINOGRAD=0: every layer through the direct kernel
     specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
     want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
-    monkeypatch.setenv("APR_WINOGRAD", "0")
-    e0 = model.Engine(W.pack_blob(he_weights, 4), 0, 8)
-    monkeypatch.delenv("APR_WINOGRAD")
-    monkeypatch.setenv("APR_WINO_MIN_CIN", "64")        # every stride-1 igemm layer through Winograd
-    e1 = model.Engine(W.pack_blob(he_weights, 4), 0, 8)
-    direct, wino = e0.infer_logits(specs), e1.infer_logits(specs)
-    e0.close(); e1.close()
-    assert np.abs(direct - want).max() <= LOGIT_TOL and np.abs(wino - want).max() <= LOGIT_TOL
-    assert np.abs(direct - wino).max() <= 2e-5
-    assert not np.array_equal(direct, wino)             # the two paths really are different arithmetic
+    blob = W.pack_blob(he_weights, 4)
+
+    def run(env, batch=8):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = model.Engine(blob, 0, batch)
+        for k in env:
+            monkeypatch.delenv(k)
+        out = e.infer_logits(specs)
+        e.close()
+        return out
+
+    direct = run({"APR_WINOGRAD": "0"})
+    default = run({})
+    unfused = run({"APR_WINO_FUSED": "0", "APR_WINO_MIN_CIN": "64"})    # every stride-1 igemm layer, three-kernel form
+    fused = run({"APR_WINO_FUSED_MAX_CIN": "512"})                      # every stride-1 igemm layer, one-kernel form
+    fused1 = run({"APR_WINO_FUSED_MAX_CIN": "512"}, batch=1)            # ragged tile blocks (6 windows in chunks of 1)
+    for got in (direct, default, unfused, fused, fused1):
+        assert np.abs(got - want).max() <= LOGIT_TOL
+    for got in (default, unfused, fused):
+        assert np.abs(direct - got).max() <= 2e-5
+        assert not np.array_equal(direct, got)          # really different arithmetic
+    assert not np.array_equal(unfused, fused)
+    assert np.array_equal(fused, fused1)                # batch size / chunking is bit-invisible

@@ -1,0 +1,95 @@
+// wino_fused_bench.cpp -- stand-alone check + timing of wino_fused_f2 against the direct igemm kernel
+// (developer tool).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I include tools/wino_fused_bench.cpp -o tools/wino_fused_bench
+//   tools/wino_fused_bench H W Cin Cout batch [reps]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../apr_amd/csrc/wino_fused.hip.h"
+
+#define CK(x) do { hipError_t r_ = (x); if (r_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(r_)); return 1; } } while (0)
+
+__global__ void maxdiff_kernel(const float *a, const float *b, size_t n, unsigned *out_bits, float *out_maxabs)
+{
+    float m = 0.f, s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float df = fabsf(a[i] - b[i]);
+        if (!(df <= 1e30f)) df = 1e30f;   // NaN (an output never written) must not hide
+        m = fmaxf(m, df);
+        s = fmaxf(s, fabsf(b[i]));
+    }
+    atomicMax(out_bits, __float_as_uint(m));
+    atomicMax(reinterpret_cast<unsigned *>(out_maxabs), __float_as_uint(s));
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { printf("usage: H W Cin Cout batch [reps]\n"); return 1; }
+    const int H = atoi(argv[1]), W = atoi(argv[2]), Cin = atoi(argv[3]), Cout = atoi(argv[4]), B = atoi(argv[5]);
+    const int reps = argc > 6 ? atoi(argv[6]) : 10;
+    if (Cin % 16 || Cout % 128) { printf("need Cin %% 16 == 0, Cout %% 128 == 0\n"); return 1; }
+    const long long M = (long long)B * H * W;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long long T = (long long)B * th * tw;
+    const size_t n_in = (size_t)B * H * W * Cin, n_out = (size_t)M * Cout, n_w = (size_t)9 * Cin * Cout;
+    std::vector<float> h_in(n_in), h_g((size_t)Cout * Cin * 9), h_w(n_w), h_b(Cout);
+    unsigned s = 12345;
+    for (auto &v : h_in) { s = s * 1664525u + 1013904223u; v = (float)(s >> 8) / 16777216.0f - 0.3f; }
+    for (auto &v : h_g) { s = s * 1664525u + 1013904223u; v = ((float)(s >> 8) / 16777216.0f - 0.5f) * 0.05f; }
+    for (auto &v : h_b) { s = s * 1664525u + 1013904223u; v = ((float)(s >> 8) / 16777216.0f - 0.5f) * 0.2f; }
+    // direct layout [tap][cin][cout]
+    for (int o = 0; o < Cout; o++)
+        for (int c = 0; c < Cin; c++)
+            for (int t = 0; t < 9; t++) h_w[((size_t)t * Cin + c) * Cout + o] = h_g[((size_t)o * Cin + c) * 9 + t];
+    std::vector<float> h_u((size_t)16 * Cin * Cout);
+    apr::wf_pack_u(h_g.data(), Cin, Cout, h_u.data());
+
+    float *d_in, *d_w, *d_u, *d_b, *d_out, *d_ref, *d_stat;
+    CK(hipMalloc(&d_in, n_in * 4)); CK(hipMalloc(&d_w, n_w * 4)); CK(hipMalloc(&d_u, h_u.size() * 4)); CK(hipMalloc(&d_b, Cout * 4));
+    CK(hipMalloc(&d_out, n_out * 4)); CK(hipMalloc(&d_ref, n_out * 4)); CK(hipMalloc(&d_stat, 8));
+    CK(hipMemcpy(d_in, h_in.data(), n_in * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_w, h_w.data(), n_w * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_u, h_u.data(), h_u.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_b, h_b.data(), Cout * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(d_out, 0xFF, n_out * 4));
+    CK(hipMemset(d_stat, 0, 8));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(apr::wino_fused_f2), hipFuncAttributeMaxDynamicSharedMemorySize, apr::WF_LDS_BYTES));
+
+    // reference: the direct implicit-GEMM kernel
+    {
+        const int tiles_n = Cout / 128;
+        const long long tiles_m = (M + 127) / 128;
+        hipLaunchKernelGGL((apr::conv3x3_igemm_f32<128, 128, 1>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, 0, d_in, d_w, d_b, d_ref, H, W, Cin, H, W, Cout, (int)M, tiles_n);
+    }
+    const int tiles_n = Cout / apr::WF_BN;
+    const long long tiles_m = (T + apr::WF_TT - 1) / apr::WF_TT;
+    auto launch = [&]() {
+        hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n);
+    };
+    launch();
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(maxdiff_kernel, dim3(2048), dim3(256), 0, 0, d_out, d_ref, n_out, reinterpret_cast<unsigned *>(d_stat), d_stat + 1);
+    float stat[2];
+    CK(hipMemcpy(stat, d_stat, 8, hipMemcpyDeviceToHost));
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; i++) launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double fl = 2.0 * (double)M * Cout * 9.0 * Cin;
+    const double flx = 2.0 * 16.0 * (double)T * Cin * Cout;
+    printf("%dx%d Cin=%d Cout=%d B=%d: %.3f ms  effective %.1f TFLOP/s  executed %.1f TFLOP/s  blocks=%lld  max|diff|=%.3e (max|ref|=%.3e)\n", H, W, Cin,
+           Cout, B, ms, fl / ms / 1e9, flx / ms / 1e9, tiles_m * tiles_n, stat[0], stat[1]);
+    if (argc > 7) return 0;   // timing-only ablation builds
+    return std::isfinite(stat[0]) && stat[0] <= 1e-4f * fmaxf(stat[1], 1.0f) ? 0 : 2;
+}
