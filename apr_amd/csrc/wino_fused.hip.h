@@ -51,6 +51,11 @@ __device__ __forceinline__ f32x2 wf_sub2(f32x2 a, f32x2 b)
 #endif
 }
 
+__device__ __forceinline__ void wf_store1(__amdgpu_buffer_rsrc_t rs, unsigned voff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, 0, 0);
+}
+
 constexpr int WF_TT = 64;                       // tiles per block
 constexpr int WF_BN = 64;                       // output channels per block
 constexpr int WF_BK = 8;                        // input channels per K step
@@ -97,21 +102,6 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
     const int g0 = bm * WF_TT;                   // first tile of the block (< T)
     const int b0 = g0 / tpw;                     // its window
 
-    if (tid < WF_TT) {
-        const int g = g0 + tid;
-        int px = -1, fl = 0;
-        if (g < T) {
-            const int tx = g % tw;
-            const int rr = g / tw;
-            const int ty = rr % th;
-            const int b = rr / th;
-            px = (b * H + 2 * ty) * W + 2 * tx;
-            fl = (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0);
-        }
-        tbl[2 * tid] = px;
-        tbl[2 * tid + 1] = fl;
-    }
-
     // ---- input patch addressing: buffer loads, zero padding through out-of-range offsets ----
     constexpr unsigned OOB = 0x80000000u;
     const float *abase = in + (((long long)b0 * H - 1) * W - 1) * (long long)Cin;
@@ -119,6 +109,7 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
     const int t_ld = tid >> 2, cp = tid & 3;     // this thread transforms tile t_ld, channels 2cp, 2cp+1 of the chunk
     unsigned voff = OOB, vmask = 0;
     {
+        int tpx = -1, tfl = 0;                   // the tile's entry of the epilogue's table, from the same divisions
         const int g = g0 + t_ld;
         if (g < T) {
             const int tx = g % tw;
@@ -127,11 +118,17 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
             const int db = rr / th - b0;
             const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
             voff = 4u * (unsigned)(((db * H + y0 + 1) * W + x0 + 1) * Cin + 2 * cp);
+            tpx = (db * H + 2 * ty) * W + 2 * tx;   // relative to the block's first window
+            tfl = (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0);
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (y0 + i >= 0 && y0 + i < H && x0 + j >= 0 && x0 + j < W) vmask |= 1u << (4 * i + j);
+        }
+        if (cp == 0) {
+            tbl[2 * t_ld] = tpx;
+            tbl[2 * t_ld + 1] = tfl;
         }
     }
     // ---- U: descriptor words for the LDS-DMA; a K step's image is contiguous (32 KiB) ----
@@ -297,6 +294,9 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
     //      A^T = [1 1 1 0; 0 1 -1 -1] ----
     const int n = bn * WF_BN + wn * 32 + li;
     const float bv = bias[n];
+    // output descriptor based at the block's first window: offsets stay 32-bit
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
+    const unsigned nb4 = 4u * (unsigned)n;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
@@ -311,15 +311,12 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
         const float y01 = fmaxf(t0[1] - t0[2] - t0[3] + bv, 0.0f);
         const float y10 = fmaxf(t1[0] + t1[1] + t1[2] + bv, 0.0f);
         const float y11 = fmaxf(t1[1] - t1[2] - t1[3] + bv, 0.0f);
-        if (px >= 0) {
-            float *o = out + (long long)px * Cout + n;
-            o[0] = y00;
-            if (fl & 2) o[Cout] = y01;
-            if (fl & 1) {
-                o[(long long)W * Cout] = y10;
-                if (fl & 2) o[(long long)(W + 1) * Cout] = y11;
-            }
-        }
+        // branch-free: pixels that do not exist get an out-of-range offset and the buffer unit drops them
+        const unsigned o0 = 4u * (unsigned)(px * Cout) + nb4;
+        wf_store1(rsO, px >= 0 ? o0 : OOB, y00);
+        wf_store1(rsO, px >= 0 && (fl & 2) ? o0 + 4u * (unsigned)Cout : OOB, y01);
+        wf_store1(rsO, px >= 0 && (fl & 1) ? o0 + 4u * (unsigned)(W * Cout) : OOB, y10);
+        wf_store1(rsO, px >= 0 && (fl & 3) == 3 ? o0 + 4u * (unsigned)((W + 1) * Cout) : OOB, y11);
     }
 }
 
