@@ -20,6 +20,7 @@ SYMBOLS = (
     "apr_last_error", "apr_prepare", "apr_prepare_batch", "apr_infer", "apr_score", "apr_score_device",
     "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable",
     "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
+    "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
 )
 
 
@@ -77,6 +78,15 @@ def lib():
     L.apr_classify.restype = C.c_int
     L.apr_classify_device.argtypes = [vp, f32p, C.c_int, C.c_double, C.c_int, f64p, vp, vp, f32p]
     L.apr_classify_device.restype = C.c_int
+    L.apr_windows_in.argtypes = [C.c_size_t, C.c_size_t]
+    L.apr_windows_in.restype = C.c_size_t
+    L.apr_sweep_files.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_double, C.c_int,
+                                  f64p, vp, vp, C.POINTER(C.c_size_t)]
+    L.apr_sweep_files.restype = C.c_int
+    L.apr_wav_data_offset.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
+    L.apr_wav_data_offset.restype = C.c_size_t
+    L.apr_bucket_hits.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]
+    L.apr_bucket_hits.restype = C.c_int
     L.apr_sync.argtypes = [vp]
     L.apr_sync.restype = C.c_int
     L.apr_engine_stream.argtypes = [vp]

@@ -74,6 +74,20 @@ struct apr_engine {
     uint8_t *d_match = nullptr;
     float *d_logits = nullptr;
 
+    // apr_sweep_files: two pinned host buffers + two device buffers, filled on a copy stream while the
+    // previous pass computes
+    hipStream_t copy_stream = nullptr;
+    uint8_t *h_pin[2] = {nullptr, nullptr};
+    uint8_t *d_pin[2] = {nullptr, nullptr};
+    double *h_probs[2] = {nullptr, nullptr};
+    int32_t *h_label[2] = {nullptr, nullptr};
+    uint8_t *h_match[2] = {nullptr, nullptr};
+    double *d_probs2[2] = {nullptr, nullptr};
+    int32_t *d_label2[2] = {nullptr, nullptr};
+    uint8_t *d_match2[2] = {nullptr, nullptr};
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    size_t pin_cap = 0;
+
     // profiling
     bool prof_on = false;
     apr_profile_slot slots[APR_PROF_SLOTS];
@@ -331,7 +345,7 @@ struct ProfScope {
         if (!e->prof_on || slot < 0) return;
         a = get_event(e); b = get_event(e);
         if (!a || !b) { a = b = nullptr; return; }
-        hipEventRecord(a, e->stream);
+        (void)hipEventRecord(a, e->stream);
         e->slots[slot].flops += flops;
         e->slots[slot].bytes += bytes;
         e->slots[slot].launches += 1;
@@ -339,7 +353,7 @@ struct ProfScope {
     ~ProfScope()
     {
         if (!a) return;
-        hipEventRecord(b, e->stream);
+        (void)hipEventRecord(b, e->stream);
         e->pending.push_back({a, b, slot});
     }
 };
@@ -589,12 +603,21 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
 void apr_engine_destroy(apr_engine *e)
 {
     if (!e) return;
-    hipSetDevice(e->device);
-    if (e->stream) hipStreamSynchronize(e->stream);
-    for (auto &p : e->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    for (auto ev : e->free_events) hipEventDestroy(ev);
-    for (void *p : e->allocs) hipFree(p);
-    if (e->stream) hipStreamDestroy(e->stream);
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto ev : e->free_events) (void)hipEventDestroy(ev);
+    for (void *p : e->allocs) (void)hipFree(p);
+    for (int b = 0; b < 2; b++) {
+        if (e->h_pin[b]) (void)hipHostFree(e->h_pin[b]);
+        if (e->h_probs[b]) (void)hipHostFree(e->h_probs[b]);
+        if (e->h_label[b]) (void)hipHostFree(e->h_label[b]);
+        if (e->h_match[b]) (void)hipHostFree(e->h_match[b]);
+        if (e->ev_h2d[b]) (void)hipEventDestroy(e->ev_h2d[b]);
+        if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -770,6 +793,106 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
         if (match) HIPCHK(e, hipMemcpyAsync(match + w0, e->d_match, nw, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
     }
+    return APR_OK;
+}
+
+
+size_t apr_windows_in(size_t nbytes, size_t stride_bytes)
+{
+    // ai/inspect.py:108-109: range(0, len(raw) - bytes_per_second, bytes_per_second)
+    if (!stride_bytes || nbytes <= stride_bytes) return 0;
+    return (nbytes - stride_bytes + stride_bytes - 1) / stride_bytes;
+}
+
+int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const size_t *nbytes, size_t stride_bytes, double trust,
+                    int empty_class, double *probs, int32_t *label, uint8_t *match, size_t *first_window)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if (n_files < 0 || (n_files && (!pcm || !nbytes)) || !stride_bytes || stride_bytes % 2) { e->err = "apr_sweep_files: bad argument"; return APR_ERR_INVALID; }
+    const int C = e->n_classes;
+    const size_t span_w = (APR_SAMPLE_SIZE + stride_bytes - 1) / stride_bytes;   // strides one window spans (2 at the 1-s hop)
+    const size_t cap_w = (size_t)e->max_batch;                                    // stream windows per pass
+    if (span_w > cap_w) { e->err = "apr_sweep_files: stride too small for max_batch"; return APR_ERR_INVALID; }
+    const size_t cap_bytes = (cap_w + span_w) * stride_bytes;
+    if (e->pin_cap < cap_bytes) {
+        if (e->pin_cap) { e->err = "apr_sweep_files: stride changed between calls on one engine"; return APR_ERR_INVALID; }
+        HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIPCHK(e, hipHostMalloc((void **)&e->h_pin[b], cap_bytes, hipHostMallocDefault));
+            HIPCHK(e, hipHostMalloc((void **)&e->h_probs[b], cap_w * C * sizeof(double), hipHostMallocDefault));
+            HIPCHK(e, hipHostMalloc((void **)&e->h_label[b], cap_w * sizeof(int32_t), hipHostMallocDefault));
+            HIPCHK(e, hipHostMalloc((void **)&e->h_match[b], cap_w, hipHostMallocDefault));
+            if ((rc = dev_alloc(e, &e->d_pin[b], cap_bytes + 16)) || (rc = dev_alloc(e, &e->d_probs2[b], cap_w * C)) ||
+                (rc = dev_alloc(e, &e->d_label2[b], cap_w)) || (rc = dev_alloc(e, &e->d_match2[b], cap_w)))
+                return rc;
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
+        }
+        e->pin_cap = cap_bytes;
+    }
+
+    // segments: [w0, w0 + nw) of one file, laid into a pass at a stride-aligned base; the span_w - 1
+    // stream windows after a segment straddle into the next one and are dropped
+    struct Seg { int file; size_t w0, nw, base_w, row; };
+    std::vector<std::vector<Seg>> passes(1);
+    size_t used = 0, row = 0;
+    for (int f = 0; f < n_files; f++) {
+        if (first_window) first_window[f] = row;
+        size_t W = apr_windows_in(nbytes[f], stride_bytes), w0 = 0;
+        while (W) {
+            const size_t room = cap_w - used;
+            if (room < 1) { passes.emplace_back(); used = 0; continue; }
+            const size_t nw = std::min(W, room);
+            passes.back().push_back({f, w0, nw, used, row});
+            used += nw + span_w - 1;       // next base; may pass cap_w: those windows are not computed
+            if (used >= cap_w) { passes.emplace_back(); used = 0; }
+            w0 += nw; W -= nw; row += nw;
+        }
+    }
+    if (first_window) first_window[n_files] = row;
+    if (passes.back().empty()) passes.pop_back();
+
+    auto drain = [&](int b, const std::vector<Seg> &ps) -> int {
+        HIPCHK(e, hipEventSynchronize(e->ev_done[b]));
+        for (const Seg &sg : ps) {
+            if (probs) memcpy(probs + sg.row * C, e->h_probs[b] + sg.base_w * C, sg.nw * C * sizeof(double));
+            if (label) memcpy(label + sg.row, e->h_label[b] + sg.base_w, sg.nw * sizeof(int32_t));
+            if (match) memcpy(match + sg.row, e->h_match[b] + sg.base_w, sg.nw);
+        }
+        return APR_OK;
+    };
+    for (size_t p = 0; p < passes.size(); p++) {
+        const int b = (int)(p & 1);
+        if (p >= 2 && (rc = drain(b, passes[p - 2]))) return rc;       // buffer b is free again
+        const std::vector<Seg> &ps = passes[p];
+        const Seg &last = ps.back();
+        const size_t n_stream = last.base_w + last.nw;                  // stream windows computed in this pass
+        const size_t bytes = (n_stream - 1) * stride_bytes + APR_SAMPLE_SIZE;
+        size_t cur = 0;
+        for (const Seg &sg : ps) {
+            const size_t base = sg.base_w * stride_bytes;
+            if (base > cur) memset(e->h_pin[b] + cur, 0, base - cur);
+            const size_t src0 = sg.w0 * stride_bytes;
+            const size_t want = (sg.nw - 1) * stride_bytes + APR_SAMPLE_SIZE;
+            const size_t have = std::min(want, nbytes[sg.file] - src0);
+            memcpy(e->h_pin[b] + base, pcm[sg.file] + src0, have);
+            cur = base + have;
+        }
+        if (bytes > cur) memset(e->h_pin[b] + cur, 0, bytes - cur);
+        HIPCHK(e, hipMemcpyAsync(e->d_pin[b], e->h_pin[b], bytes, hipMemcpyHostToDevice, e->copy_stream));
+        HIPCHK(e, hipEventRecord(e->ev_h2d[b], e->copy_stream));
+        HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
+        if ((rc = run_frontend(e, APR_FLAVOUR_GO, e->d_pin[b], bytes, (int)n_stream, stride_bytes, e->d_spec))) return rc;
+        if ((rc = run_cnn(e, e->d_spec, (int)n_stream, trust, empty_class, nullptr, e->d_probs2[b], e->d_label2[b], e->d_match2[b]))) return rc;
+        HIPCHK(e, hipMemcpyAsync(e->h_probs[b], e->d_probs2[b], n_stream * C * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->h_label[b], e->d_label2[b], n_stream * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->h_match[b], e->d_match2[b], n_stream, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipEventRecord(e->ev_done[b], e->stream));
+    }
+    for (size_t p = passes.size() >= 2 ? passes.size() - 2 : 0; p < passes.size(); p++)
+        if ((rc = drain((int)(p & 1), passes[p]))) return rc;
     return APR_OK;
 }
 

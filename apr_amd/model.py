@@ -181,6 +181,21 @@ class Engine:
                                       probs.ctypes.data, label.ctypes.data, match.ctypes.data))
         return dict(probs=probs, label=label, match=match)
 
+    def sweep_files(self, files, stride: int = BytesPerSecond, trust: float = 0.5, empty_class: int = -1):
+        """apr_sweep_files over a list of host PCM buffers -> dict(probs, label, match, first_window [n_files+1])."""
+        bufs = [_as_u8(f) for f in files]
+        n = len(bufs)
+        ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(n, 1))(*[b.size for b in bufs])
+        first = (C.c_size_t * (n + 1))()
+        total = sum(windows_in(b.size, stride) for b in bufs)
+        probs = np.empty((total, self.num_classes), np.float64)
+        label = np.empty(total, np.int32)
+        match = np.empty(total, np.uint8)
+        self._chk(self._lib.apr_sweep_files(self._h, n, ptrs, lens, stride, trust, empty_class, probs.ctypes.data,
+                                            label.ctypes.data, match.ctypes.data, first))
+        return dict(probs=probs, label=label, match=match, first_window=np.asarray(list(first), np.int64))
+
     # ---- device-resident entry points (torch tensors on this engine's GPU) ----
     def score_device(self, d_pcm, total_bytes: int, n_windows: int, stride: int, trust: float, empty_class: int,
                      d_probs=None, d_label=None, d_match=None, d_logits=None) -> None:

@@ -139,6 +139,37 @@ def read_dat(path: str) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------------------------
+# either side of the path: RIFF header of the live stream, one-minute hit buckets (host only)
+# ----------------------------------------------------------------------------------------------
+def wav_data_offset(buf) -> dict:
+    """apr_wav_data_offset: where the PCM payload of a RIFF/WAVE stream starts (0 = raw PCM) + fmt fields.
+    The reference does not strip the header of ffmpeg's `-f wav -` stream (src/ffmpeg/ffmpeg.go:111-114,
+    src/daemon/daemon.go:151-154)."""
+    import ctypes as C
+    from . import _capi
+    b = np.ascontiguousarray(np.frombuffer(buf, np.uint8) if not isinstance(buf, np.ndarray) else buf).view(np.uint8).reshape(-1)
+    sr, ch, bits = C.c_uint32(), C.c_uint16(), C.c_uint16()
+    off = _capi.lib().apr_wav_data_offset(b.ctypes.data, b.size, C.byref(sr), C.byref(ch), C.byref(bits))
+    return dict(offset=int(off), sample_rate=sr.value, channels=ch.value, bits_per_sample=bits.value)
+
+
+def bucket_hits(label, match, n_classes: int, windows_per_bucket: int = 60) -> np.ndarray:
+    """apr_bucket_hits: [n_buckets, n_classes] u8, 1 iff the class matched at least once in that minute
+    (docs/usage/review.md:48-53: '1 clap or 999 claps within 1 minute is logged as one hit')."""
+    from . import _capi
+    lab = np.ascontiguousarray(label, np.int32)
+    mat = np.ascontiguousarray(match, np.uint8)
+    if lab.shape != mat.shape or lab.ndim != 1:
+        raise ValueError("label and match must be 1-D and of equal length")
+    nb = (lab.size + windows_per_bucket - 1) // windows_per_bucket
+    hits = np.zeros((nb, n_classes), np.uint8)
+    rc = _capi.lib().apr_bucket_hits(lab.ctypes.data, mat.ctypes.data, lab.size, n_classes, windows_per_bucket, hits.ctypes.data)
+    if rc != 0:
+        raise _capi.AprError(rc, "apr_bucket_hits: bad argument")
+    return hits
+
+
+# ----------------------------------------------------------------------------------------------
 # multi-model fan-out: one spectrogram, every configured model
 # (src/daemon/daemon.go:93-99,132-136 and ai/inspect.py:133-159)
 # ----------------------------------------------------------------------------------------------

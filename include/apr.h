@@ -166,6 +166,45 @@ int apr_classify(apr_engine *e, const float *spec, int batch, double trust, int 
 int apr_classify_device(apr_engine *e, const float *d_spec, int batch, double trust, int empty_class,
                         double *d_probs, int32_t *d_label, uint8_t *d_match, float *d_logits);
 
+/*
+ * Number of 2-s windows a recording of `nbytes` yields at hop `stride_bytes`:
+ * len(range(0, nbytes - stride, stride)) of ai/inspect.py:108-109 (T whole seconds -> T-1 windows,
+ * the daemon's count too: src/daemon/daemon.go:115-119).
+ */
+size_t apr_windows_in(size_t nbytes, size_t stride_bytes);
+
+/*
+ * Sweep over a list of recordings held in host memory: the loop of ai/inspect.py:73-112 (and of the
+ * daemon, src/daemon/daemon.go:104-136) for n_files buffers at once.  File f contributes
+ * apr_windows_in(nbytes[f], stride_bytes) windows, none of which crosses into another file; rows are
+ * written file after file, first_window[f] (n_files + 1 entries, optional) giving each file's first
+ * row.  Files are packed back to back into full GPU passes (a long file spans several passes, short
+ * files share one), through two pinned staging buffers: the host->device copy of pass p+1 runs on a
+ * copy stream while pass p computes.  probs/label/match as in apr_score; host pointers; synchronous.
+ * The multi-GPU form is one process per GPU, each sweeping its own files (apr_amd/sweep.py:
+ * shard_files + gather_scores over RCCL).
+ */
+int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const size_t *nbytes, size_t stride_bytes,
+                    double trust, int empty_class, double *probs, int32_t *label, uint8_t *match, size_t *first_window);
+
+/*
+ * Offset of the PCM payload in a RIFF/WAVE byte stream (0 if `buf` is not RIFF or holds no data
+ * chunk yet); fills the fmt fields when non-NULL.  The reference feeds `ffmpeg -f wav -` straight
+ * into its 96000-byte segment reader without skipping the header (src/ffmpeg/ffmpeg.go:111-114,
+ * src/daemon/daemon.go:151-154); a caller that wants the first window clean skips this many bytes.
+ * Host only, no GPU.
+ */
+size_t apr_wav_data_offset(const uint8_t *buf, size_t n, uint32_t *sample_rate, uint16_t *channels, uint16_t *bits_per_sample);
+
+/*
+ * Report bucketing: hits[b][c] = 1 iff some window k in [b*wpb, (b+1)*wpb) has match[k] and
+ * label[k] == c -- "1 clap or 999 claps within 1 minute is logged as one hit"
+ * (docs/usage/review.md:48-53; the reference's code does not implement it).  wpb = 60 at the 1-s hop.
+ * hits: [ceil(n_windows / wpb)][n_classes] bytes, caller-allocated.  Host only, no GPU.
+ */
+int apr_bucket_hits(const int32_t *label, const uint8_t *match, size_t n_windows, int n_classes, size_t windows_per_bucket,
+                    uint8_t *hits);
+
 /* Block until all work queued on this engine's stream has finished. */
 int apr_sync(apr_engine *e);
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from apr_amd import model, weights as W
+from apr_amd import model, sweep, weights as W
 from apr_amd._capi import AprError, FLAVOUR_GO, FLAVOUR_LIBROSA, WARN_OVERFLOW, WARN_UNDERFLOW
 from conftest import GOLDEN, LABELS
 
@@ -264,3 +264,27 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
         assert not np.array_equal(direct, got)          # really different arithmetic
     assert not np.array_equal(unfused, fused)
     assert np.array_equal(fused, fused1)                # batch size / chunking is bit-invisible
+
+
+def test_sweep_files_equals_per_file_score(he_weights):
+    # ragged list: packed into shared passes, split across passes, empty and too-short files, short tail windows
+    eng = model.Engine(W.pack_blob(he_weights, 4), 0, 16)
+    secs = [5.0, 1.0, 0.5, 3.3, 40.0, 0.0, 2.0, 2.01]
+    files = [model.synth_pcm(3, i, int(np.ceil(s)) if s else 1)[: int(s * 48000)] for i, s in enumerate(secs)]
+    got = eng.sweep_files(files, trust=0.4, empty_class=2)
+    counts = [sweep.windows_in(f.size * 2) for f in files]
+    assert counts == [4, 0, 0, 3, 39, 0, 1, 2]
+    assert got["first_window"].tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
+    assert got["label"].shape == (sum(counts),)
+    for i, f in enumerate(files):
+        if not counts[i]:
+            continue
+        want = eng.score(f, counts[i], trust=0.4, empty_class=2)
+        a, b = got["first_window"][i], got["first_window"][i + 1]
+        assert np.array_equal(got["probs"][a:b], want["probs"])      # batch composition is bit-invisible
+        assert np.array_equal(got["label"][a:b], want["label"])
+        assert np.array_equal(got["match"][a:b], want["match"])
+    again = eng.sweep_files(files[:4], trust=0.4, empty_class=2)      # staging buffers are reused across calls
+    assert np.array_equal(again["probs"], got["probs"][:7])
+    assert eng.sweep_files([], trust=0.4)["label"].shape == (0,)
+    eng.close()

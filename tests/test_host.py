@@ -131,3 +131,51 @@ def test_synth_pcm_deterministic_and_seekable():
     long = model.synth_pcm(0, 0, 200)
     zero_run = np.max(np.diff(np.nonzero(np.concatenate([[1], long != 0, [1]]))[0]))
     assert zero_run >= 2400                              # exact-zero stretches exist
+
+
+def _wav(fmt_extra=b"", chunks=(), data_size=None, payload=b"\x01\x00\x02\x00"):
+    import struct
+    fmt = struct.pack("<HHIIHH", 1, 1, 48000, 96000, 2, 16) + fmt_extra
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + (b"\x00" if len(fmt) & 1 else b"")
+    for cid, c in chunks:
+        body += cid + struct.pack("<I", len(c)) + c + (b"\x00" if len(c) & 1 else b"")
+    body += b"data" + struct.pack("<I", len(payload) if data_size is None else data_size)
+    return b"RIFF" + struct.pack("<I", 0xFFFFFFFF) + body + payload, len(body) + 8
+
+
+def test_wav_data_offset():
+    # ffmpeg's streamed WAV: LIST/INFO chunk before data, sizes 0xFFFFFFFF (src/ffmpeg/ffmpeg.go:111-114)
+    raw, off = _wav(chunks=[(b"LIST", b"INFOISFT\x0e\x00\x00\x00Lavf58.76.100\x00")], data_size=0xFFFFFFFF)
+    got = sweep.wav_data_offset(raw)
+    assert got == dict(offset=off, sample_rate=48000, channels=1, bits_per_sample=16)
+    assert raw[off:off + 4] == b"\x01\x00\x02\x00"
+    plain, off2 = _wav()
+    assert sweep.wav_data_offset(plain)["offset"] == off2 == 44        # the canonical 44-byte header
+    odd, off3 = _wav(chunks=[(b"junk", b"abc")])                         # odd-sized chunk is padded to a word
+    assert sweep.wav_data_offset(odd)["offset"] == off3
+    assert sweep.wav_data_offset(np.zeros(1000, np.int16))["offset"] == 0      # raw PCM: nothing to skip
+    assert sweep.wav_data_offset(plain[:30])["offset"] == 0                     # header cut short: no data chunk yet
+    assert sweep.wav_data_offset(b"")["offset"] == 0
+
+
+def test_bucket_hits_one_hit_per_minute():
+    label = np.full(150, 2, np.int32)
+    match = np.zeros(150, np.uint8)
+    label[[3, 4, 59]] = 0; match[[3, 4, 59]] = 1          # three claps in minute 0 -> one hit
+    label[61] = 3; match[61] = 1                           # one in minute 1
+    label[130] = 1                                         # not a match (below trust): ignored
+    label[140] = -1; match[140] = 1                        # no label: ignored
+    hits = sweep.bucket_hits(label, match, 4)
+    assert hits.shape == (3, 4)
+    assert hits.tolist() == [[1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 0, 0]]
+    assert sweep.bucket_hits(np.zeros(0, np.int32), np.zeros(0, np.uint8), 4).shape == (0, 4)
+    with pytest.raises(ValueError):
+        sweep.bucket_hits(label, match[:10], 4)
+
+
+def test_c_windows_in_matches_inspect_py():
+    L = _capi.lib()
+    for n in [0, 1, 95999, 96000, 96001, 191999, 192000, 192001, 288000, 5760000, 57600000 + 17]:
+        assert L.apr_windows_in(n, 96000) == sweep.windows_in(n) == len(range(0, max(n - 96000, 0), 96000))
+    assert L.apr_windows_in(10 * 192000, 192000) == sweep.windows_in(10 * 192000, 192000) == 9
+    assert L.apr_windows_in(1000, 0) == 0
