@@ -6,7 +6,8 @@
 //   * in src/model/model.go the bodies of Prepare (model.go:86-184) and Infer
 //     (model.go:188-229) and the go-dsp / onnx-go imports are removed; the constants,
 //     OnnxModel, Train, Load, softmax and normalizeAudio stay exactly as they are,
-//   * this file is added next to it and supplies Prepare, Infer and the new ScoreBatch.
+//   * this file is added next to it and supplies Prepare, Infer and the new ScoreBatch,
+//     SweepFiles, WavDataOffset and BucketHits (go 1.24 in src/go.mod:3 has runtime.Pinner).
 // The exported surface of the package is therefore unchanged; every number is computed
 // behind the C ABI except the f64 softmax + label map, which remain the reference's own.
 //
@@ -25,6 +26,7 @@ import (
 	"dtrack/ffmpeg"
 	"dtrack/log"
 
+	"runtime"
 	"sync"
 	"unsafe"
 
@@ -168,4 +170,102 @@ func ScoreBatch(inferModel OnnxModel, pcm []byte, trust float64) (probs [][]floa
 		match[k] = m[k] != 0
 	}
 	return
+}
+
+// SweepFiles scores a list of decoded recordings in full GPU passes (short files share a pass, long
+// files span several; no window crosses a file): first[f] is the first row of file f in
+// label/match/probs, first[len(files)] the total.  The host->device copies run on a copy stream
+// while the previous pass computes (apr_sweep_files).
+func SweepFiles(inferModel OnnxModel, files [][]byte, trust float64) (probs [][]float64, label []int32, match []bool, first []int) {
+	e := engineFor(inferModel)
+	nf := len(files)
+	first = make([]int, nf+1)
+	if nf == 0 {
+		return
+	}
+	empty := -1
+	for i, l := range inferModel.Labels {
+		if l == "empty" {
+			empty = i
+		}
+	}
+	// the pointer table lives in C memory; the recordings themselves are pinned for the call
+	// (cgo forbids passing Go memory that holds Go pointers)
+	ptrs := (*[1 << 28]*C.uint8_t)(C.malloc(C.size_t(nf) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:nf:nf]
+	lens := (*[1 << 28]C.size_t)(C.malloc(C.size_t(nf) * C.size_t(unsafe.Sizeof(C.size_t(0)))))[:nf:nf]
+	cfirst := (*[1 << 28]C.size_t)(C.malloc(C.size_t(nf+1) * C.size_t(unsafe.Sizeof(C.size_t(0)))))[: nf+1 : nf+1]
+	defer C.free(unsafe.Pointer(&ptrs[0]))
+	defer C.free(unsafe.Pointer(&lens[0]))
+	defer C.free(unsafe.Pointer(&cfirst[0]))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	total := 0
+	for f, b := range files {
+		lens[f] = C.size_t(len(b))
+		ptrs[f] = nil
+		if len(b) > 0 {
+			pin.Pin(&b[0])
+			ptrs[f] = (*C.uint8_t)(unsafe.Pointer(&b[0]))
+		}
+		total += int(C.apr_windows_in(C.size_t(len(b)), C.size_t(ffmpeg.BytesPerSecond)))
+	}
+	flat := make([]float64, total*e.nc+1)
+	label = make([]int32, total+1)
+	m := make([]uint8, total+1)
+	e.mu.Lock()
+	rc := C.apr_sweep_files(e.h, C.int(nf), &ptrs[0], &lens[0], C.size_t(ffmpeg.BytesPerSecond), C.double(trust), C.int(empty),
+		(*C.double)(unsafe.Pointer(&flat[0])), (*C.int32_t)(unsafe.Pointer(&label[0])), (*C.uint8_t)(unsafe.Pointer(&m[0])), &cfirst[0])
+	e.mu.Unlock()
+	if rc != 0 {
+		log.Die("Inference failed: %v", lastErr(e.h))
+	}
+	label = label[:total]
+	probs = make([][]float64, total)
+	match = make([]bool, total)
+	for k := 0; k < total; k++ {
+		probs[k] = flat[k*e.nc : (k+1)*e.nc]
+		match[k] = m[k] != 0
+	}
+	for f := range first {
+		first[f] = int(cfirst[f])
+	}
+	return
+}
+
+// WavDataOffset reports where the PCM payload of ffmpeg's `-f wav -` stream starts (0 for raw PCM).
+// The reference reads that stream from byte 0 (ffmpeg.go:111-114, daemon.go:151-154); skipping this
+// many bytes first keeps the RIFF header out of the first window.
+func WavDataOffset(head []byte) int {
+	if len(head) == 0 {
+		return 0
+	}
+	return int(C.apr_wav_data_offset((*C.uint8_t)(unsafe.Pointer(&head[0])), C.size_t(len(head)), nil, nil, nil))
+}
+
+// BucketHits folds per-window matches into one hit per class per minute (docs/usage/review.md:48-53).
+func BucketHits(label []int32, match []bool, nClasses int) [][]bool {
+	n := len(label)
+	nb := (n + 59) / 60
+	out := make([][]bool, nb)
+	for b := range out {
+		out[b] = make([]bool, nClasses)
+	}
+	if n == 0 {
+		return out
+	}
+	m := make([]uint8, n)
+	for k, v := range match {
+		if v {
+			m[k] = 1
+		}
+	}
+	hits := make([]uint8, nb*nClasses)
+	C.apr_bucket_hits((*C.int32_t)(unsafe.Pointer(&label[0])), (*C.uint8_t)(unsafe.Pointer(&m[0])), C.size_t(n), C.int(nClasses), 60,
+		(*C.uint8_t)(unsafe.Pointer(&hits[0])))
+	for b := 0; b < nb; b++ {
+		for c := 0; c < nClasses; c++ {
+			out[b][c] = hits[b*nClasses+c] != 0
+		}
+	}
+	return out
 }

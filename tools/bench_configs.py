@@ -4,6 +4,8 @@
   config 4  live mode: 256 concurrent streams, one 1-s segment each per tick, window = previous
             segment || new segment (src/daemon/daemon.go:104-125); p50/p99 from segment arrival
             (host memory) to labels (host memory), and the sustained windows/s.
+  host sweep  PCIe-inclusive rate of apr_sweep_files: recordings in pageable host memory -> pinned
+            double-buffered staging -> GPU -> labels in host memory (never the headline number).
   config 5  training-set preprocessing: 10 000 tagged .dat clips (192 000 B each) -> librosa-flavour
             log-mel [10000,1,128,188] (ai/train.py:36-52), clips already in HBM.
 Prints one JSON line per config.
@@ -24,6 +26,8 @@ def main():
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--ticks", type=int, default=40)
     ap.add_argument("--clips", type=int, default=10000)
+    ap.add_argument("--sweep-files", type=int, default=30)
+    ap.add_argument("--sweep-seconds", type=int, default=600)
     args = ap.parse_args()
     import torch
     from apr_amd import model, sweep, weights as W
@@ -49,6 +53,21 @@ def main():
                       "latency_ms_max": float(lat.max()), "real_time_budget_ms": 1000.0,
                       "sustained_windows_per_s": float(args.streams / (np.mean(lat) * 1e-3)),
                       "note": "host->device copy of 256 x 192000 B, fused score, device->host of labels inside each tick"}),
+          flush=True)
+    eng.close()
+
+    # ---------------- host-pointer sweep (PCIe inclusive) ----------------
+    eng = model.Engine(W.pack_blob(W.random_init(C, 0, "he"), C), 0, 1024)
+    files = [model.synth_pcm(0, f, args.sweep_seconds) for f in range(args.sweep_files)]
+    eng.sweep_files(files[:2], trust=0.5, empty_class=2)           # warm-up: allocates the staging buffers
+    t0 = time.perf_counter()
+    res = eng.sweep_files(files, trust=0.5, empty_class=2)
+    dt = time.perf_counter() - t0
+    nwin = int(res["label"].size)
+    print(json.dumps({"config": "host sweep", "files": args.sweep_files, "seconds_per_file": args.sweep_seconds, "windows": nwin,
+                      "s": dt, "audio_hours_per_s": nwin / 3600.0 / dt, "pcm_GBps": sum(f.nbytes for f in files) / dt / 1e9,
+                      "matches": int(res["match"].sum()),
+                      "note": "apr_sweep_files: pageable host PCM -> pinned staging -> H2D on a copy stream overlapped with compute"}),
           flush=True)
     eng.close()
 
