@@ -112,6 +112,10 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rs, unsigned voff, int soff, 
 //   MODE 1 runs the same pipeline as a batch of plain GEMMs (the Winograd domain):
 //   blockIdx.y = transform position pos, out[pos][M][Cout] = in[pos][M][Cin] x wt[pos][Cin][Cout],
 //   one "tap", no padding, raw stores (bias/ReLU belong to the output transform).
+//   MODE 2 is the convolution split along K for grids that are too small to fill the chip (a
+//   single clip: layer 12 has 8 tiles of 576 K steps): blockIdx.y = split s takes K steps
+//   [KT s / S, KT (s+1) / S) and stores its raw partial sums to out[s][M][Cout];
+//   splitk_reduce_kernel adds them in split order (deterministic) with bias + ReLU.
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int STRIDE, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restrict__ in,
@@ -155,18 +159,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     //      load instead of 64-bit pointer arithmetic.  Zero padding and rows past M use an
     //      out-of-range offset: the buffer unit returns 0 for those lanes.
     constexpr unsigned OOB = 0x80000000u;            // >= num_records of the A descriptor
-    constexpr int TAPS = MODE == 0 ? 9 : 1;
+    constexpr int TAPS = MODE != 1 ? 9 : 1;
     const int p0 = bm * BM;                          // first output pixel of this block (< M)
-    const long long b0 = MODE == 0 ? (p0 / Wo) / Ho : 0;   // its window
+    const long long b0 = MODE != 1 ? (p0 / Wo) / Ho : 0;   // its window
     if (MODE == 1) {                                 // batched GEMM: this block's problem
         in += (size_t)blockIdx.y * M * Cin;
         wt += (size_t)blockIdx.y * Cin * Cout;
         out += (size_t)blockIdx.y * M * Cout;
     }
+    if (MODE == 2) out += (size_t)blockIdx.y * M * Cout;   // this split's partial sums
     // descriptor base = one row and one column before window b0's image, so every valid
     // tap has a non-negative offset (the base itself may lie before `in`; never dereferenced);
     // MODE 1: the block's first row
-    const float *abase = MODE == 0 ? in + ((b0 * H - 1) * W - 1) * (long long)Cin : in + (long long)p0 * Cin;
+    const float *abase = MODE != 1 ? in + ((b0 * H - 1) * W - 1) * (long long)Cin : in + (long long)p0 * Cin;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x40000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)(wt + (size_t)bn * BN), 0, 0x7FFFFFFF, 0x00020000);
 
@@ -212,13 +217,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 
     const int cchunks = Cin / BK;
     const int KT = TAPS * cchunks;
+    // K steps of this block: all of them, or this split's share (gridDim.y <= KT, host-checked)
+    const int kt0 = MODE == 2 ? (int)(((long long)KT * blockIdx.y) / gridDim.y) : 0;
+    const int kt1 = MODE == 2 ? (int)(((long long)KT * (blockIdx.y + 1)) / gridDim.y) : KT;
 
     f32x4 ra[AROWS], rb[BPASS];
 #define APR_LOAD_TILES(KT_)                                                                              \
     {                                                                                                    \
         const int tap_ = (KT_) / cchunks;                                                                \
         const int c0_ = ((KT_) - tap_ * cchunks) * BK;                                                   \
-        const int soffA_ = MODE == 0 ? 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_) : 4 * c0_;        \
+        const int soffA_ = MODE != 1 ? 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_) : 4 * c0_;        \
         const int soffB_ = 4 * (KT_) * BK * Cout;                                                        \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
@@ -257,8 +265,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    APR_LOAD_TILES(0)
-    if (APR_EXP_BDMA) APR_DMA_B(0, 0)
+    APR_LOAD_TILES(kt0)
+    if (APR_EXP_BDMA) APR_DMA_B(kt0, 0)
 #pragma unroll
     for (int i = 0; i < AROWS; i++) APR_STORE_A(0, i)
     if (!APR_EXP_BDMA) {
@@ -308,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     }
 
     int cur = 0;
-    int kt = 0;
-    for (; kt < KT - 1; kt++) APR_KSTEP(true)
+    int kt = kt0;
+    for (; kt < kt1 - 1; kt++) APR_KSTEP(true)
     APR_KSTEP(false)
 #undef APR_KSTEP
 
@@ -346,6 +354,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #undef APR_STORE_A
 #undef APR_STORE_B
 #undef APR_DMA_B
+
+// ---------------------------------------------------------------------------------------------
+// split-K tail: out[p][n] = relu(bias[n] + part[0][p][n] + part[1][p][n] + ...), splits added in
+// index order so the result does not depend on scheduling.  n4 = M * Cout / 4 float4 elements.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                            float *__restrict__ out, long long n4, int cout4, int nsplit)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 a = *reinterpret_cast<const f32x4 *>(bias + 4 * (i % cout4));
+        for (int s = 0; s < nsplit; s++) a += *reinterpret_cast<const f32x4 *>(part + 4 * (s * n4 + i));
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4 *>(out + 4 * i) = __builtin_elementwise_max(a, zero);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // head: act [B][P][F] (NHWC, P = 2*3 pixels, F = 1024) -> max over P -> logits = Wfc feat + b

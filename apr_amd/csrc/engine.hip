@@ -36,7 +36,8 @@ struct Layer {
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
     int th = 0, tw = 0;     // 2x2-output tiles per window
     int wbm_tile = 128;
-    int slot = -1, slot_in = -1, slot_out = -1;   // profile slots of its kernels
+    int ksplit = 1;         // > 1: direct kernel split along K (latency engines), partial sums in d_part
+    int slot = -1, slot_in = -1, slot_out = -1;   // profile slots of its kernels (slot_out: also the split-K reduce)
 };
 
 struct ProfPair {
@@ -65,6 +66,7 @@ struct apr_engine {
     float *d_act[2] = {nullptr, nullptr};
     float *d_wfc = nullptr, *d_bfc = nullptr;
     float *d_V = nullptr, *d_M = nullptr;   // Winograd-domain activations [16][T][Cin] / [16][T][Cout]
+    float *d_part = nullptr;                // split-K partial sums [ksplit][M][Cout]
 
     // staging for the host-pointer entry points
     uint8_t *d_pcm = nullptr;
@@ -246,7 +248,9 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     if (3 * (int)pm.convs.size() + 3 > APR_PROF_SLOTS) { e->err = "too many conv layers"; return APR_ERR_MODEL; }
     if (pm.features > 1024 || pm.features % 4) { e->err = "unsupported classifier width"; return APR_ERR_MODEL; }
     int h = kNmels, w = kSpecFrames, rc;
-    size_t act_max = 0, v_max = 0, m_max = 0;
+    size_t act_max = 0, v_max = 0, m_max = 0, part_max = 0;
+    const char *senv = getenv("APR_SPLITK");
+    const bool splitk_on = !(senv && senv[0] == '0');
     // APR_WINOGRAD=0 disables the Winograd path; APR_WINO_MIN_CIN moves its channel threshold
     const char *wenv = getenv("APR_WINOGRAD");
     const bool wino_on = !(wenv && wenv[0] == '0');
@@ -274,6 +278,19 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             // Decided once from max_batch so that a layer always runs the same instantiation.
             const long long m_full = (long long)e->max_batch * L.hout * L.wout;
             if (L.bn_tile == 128 && ((m_full + 127) / 128) * (cv.cout / 128) < 1024) L.bm_tile = 64;
+            // Latency engines (max_batch <= 4, the daemon's one-clip-per-call pattern): the late layers have
+            // a handful of tiles with hundreds of K steps each; split K over enough workgroups to fill the
+            // chip.  Only there, so that every throughput engine keeps one summation order whatever its
+            // max_batch (chunking stays bit-invisible); APR_SPLITK=0 turns it off.
+            if (splitk_on && e->max_batch <= 4) {
+                const long long blocks = ((m_full + L.bm_tile - 1) / L.bm_tile) * (cv.cout / L.bn_tile);
+                const int kt = 9 * cv.cin / 16;
+                int sp = (int)std::min<long long>(512 / std::max<long long>(blocks, 1), kt / 8);
+                if (sp >= 2) {
+                    L.ksplit = std::min(sp, 64);
+                    part_max = std::max(part_max, (size_t)L.ksplit * (size_t)m_full * cv.cout);
+                }
+            }
         }
         // re-layout [cout][cin][3][3] -> [tap][cin][cout]
         std::vector<float> wt((size_t)9 * cv.cin * cv.cout);
@@ -286,6 +303,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             wf_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
             L.wino = 3;
+            L.ksplit = 1;
             L.th = (L.hout + 1) / 2;
             L.tw = (L.wout + 1) / 2;
         } else if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= wino_min_cin && cv.cout % 128 == 0) {
@@ -306,6 +324,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
                 }
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
             L.wino = 2;
+            L.ksplit = 1;
             L.th = (L.hout + 1) / 2;
             L.tw = (L.wout + 1) / 2;
             const long long t_full = (long long)e->max_batch * L.th * L.tw;
@@ -323,6 +342,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     if ((rc = dev_upload(e, &e->d_wfc, pm.fc_w)) || (rc = dev_upload(e, &e->d_bfc, pm.fc_b))) return rc;
     for (int i = 0; i < 2; i++)
         if ((rc = dev_alloc(e, &e->d_act[i], act_max * (size_t)e->max_batch))) return rc;
+    if (part_max && (rc = dev_alloc(e, &e->d_part, part_max))) return rc;
     if (v_max && ((rc = dev_alloc(e, &e->d_V, v_max * (size_t)e->max_batch)) || (rc = dev_alloc(e, &e->d_M, m_max * (size_t)e->max_batch)))) return rc;
     return APR_OK;
 }
@@ -377,16 +397,23 @@ int run_frontend(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_
                  float *d_out)
 {
     const FrontendTables &T = e->tab[flavour];
-    const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
+    // a handful of windows (live clips): one frame per wave and one column chunk per block, so that the
+    // front end's latency is one frame's, not four; the arithmetic per frame / element is the same code
+    const bool few = n_windows <= 8;
+    const int fpb = few ? 4 : kFramesPerBlock;
+    const int groups = (T.n_frames + fpb - 1) / fpb;
     {
         ProfScope ps(e, 0, (double)n_windows * T.n_frames * 5.0 * kNfft * 11.0 + 2.0 * T.nnz * T.n_frames * n_windows,
                      (double)n_windows * (std::min<size_t>(stride, APR_SAMPLE_SIZE) + (double)T.n_frames * kNmels * 4));
-        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride,
-                           n_windows, T, e->d_melT);
+        if (few)
+            hipLaunchKernelGGL(stft_mel_kernel<4>, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, e->d_melT);
+        else
+            hipLaunchKernelGGL(stft_mel_kernel<kFramesPerBlock>, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride,
+                               n_windows, T, e->d_melT);
     }
     {
         ProfScope ps(e, 1, 0.0, (double)n_windows * ((double)T.n_frames * kNmels * 4 + APR_SPEC_ELEMS * 4));
-        hipLaunchKernelGGL(db_norm_kernel, dim3(n_windows), dim3(256), 0, e->stream, e->d_melT, n_windows, T.n_frames,
+        hipLaunchKernelGGL(db_norm_kernel, dim3(n_windows, few ? 6 : 1), dim3(256), 0, e->stream, e->d_melT, n_windows, T.n_frames,
                            T.librosa, d_out);
     }
     HIPCHK(e, hipGetLastError());
@@ -400,6 +427,15 @@ void launch_igemm(apr_engine *e, const Layer &L, const float *in, float *out, lo
     const long long tiles_m = (M + BM - 1) / BM;   // M < 2^31: max_batch is capped at create
     hipLaunchKernelGGL((conv3x3_igemm_f32<BM, BN, S>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, e->stream, in,
                        L.d_w, L.d_b, out, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n);
+}
+
+template <int BM, int BN, int S>
+void launch_igemm_splitk(apr_engine *e, const Layer &L, const float *in, long long M)
+{
+    const int tiles_n = L.cout / BN;
+    const long long tiles_m = (M + BM - 1) / BM;
+    hipLaunchKernelGGL((conv3x3_igemm_f32<BM, BN, S, 2>), dim3((unsigned)(tiles_m * tiles_n), (unsigned)L.ksplit), dim3(256), 0, e->stream, in,
+                       L.d_w, L.d_b, e->d_part, L.hin, L.win, L.cin, L.hout, L.wout, L.cout, (int)M, tiles_n);
 }
 
 template <int BM>
@@ -449,6 +485,25 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
                 ProfScope ps(e, L.slot_out, 0.0, 4.0 * (16.0 * T * L.cout + (double)M * L.cout));
                 hipLaunchKernelGGL(wino_output_f2, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
                                    e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
+            }
+            in = out;
+            continue;
+        }
+        if (L.ksplit > 1) {
+            {
+                ProfScope ps(e, L.slot, flops, bytes + 4.0 * L.ksplit * (double)M * L.cout);
+                if (L.bn_tile == 128) {
+                    if (L.bm_tile == 64) { if (L.stride == 1) launch_igemm_splitk<64, 128, 1>(e, L, in, M); else launch_igemm_splitk<64, 128, 2>(e, L, in, M); }
+                    else { if (L.stride == 1) launch_igemm_splitk<128, 128, 1>(e, L, in, M); else launch_igemm_splitk<128, 128, 2>(e, L, in, M); }
+                } else {
+                    if (L.stride == 1) launch_igemm_splitk<128, 64, 1>(e, L, in, M); else launch_igemm_splitk<128, 64, 2>(e, L, in, M);
+                }
+            }
+            {
+                const long long n4 = M * L.cout / 4;
+                ProfScope ps(e, L.slot_out, 0.0, 4.0 * (L.ksplit + 1.0) * (double)M * L.cout);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 4096)), dim3(256), 0, e->stream, e->d_part,
+                                   L.d_b, out, n4, L.cout / 4, L.ksplit);
             }
             in = out;
             continue;
@@ -580,12 +635,15 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
                 add_slot(e, "wino_input_f2", (int)l + 1);
                 snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 1>", L.wbm_tile);
             } else if (l == 0) snprintf(nm, sizeof nm, "conv1_kernel");
-            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d, 0>", L.bm_tile, L.bn_tile, L.stride);
+            else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d, %d>", L.bm_tile, L.bn_tile, L.stride, L.ksplit > 1 ? 2 : 0);
             L.slot = e->n_slots;
             add_slot(e, nm, (int)l + 1);
             if (L.wino == 2) {
                 L.slot_out = e->n_slots;
                 add_slot(e, "wino_output_f2", (int)l + 1);
+            } else if (L.ksplit > 1) {
+                L.slot_out = e->n_slots;
+                add_slot(e, "splitk_reduce_kernel", (int)l + 1);
             }
         }
         e->head_slot = e->n_slots;

@@ -23,7 +23,7 @@ constexpr int kHop = 512;
 constexpr int kNmels = 128;
 constexpr int kSpecFrames = 188;
 constexpr int kSampleBytes = 192000;
-constexpr int kFramesPerBlock = 16;   // 4 waves x 4 frames
+constexpr int kFramesPerBlock = 16;   // 4 waves x 4 frames (throughput); 4 = one frame per wave for single clips
 constexpr int kMaxNnz = 2304;         // CSR capacity (go lens: 1892, librosa: ~2.1k)
 
 struct FrontendTables {
@@ -96,6 +96,7 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr int kLdsWave = 1104;   // padded complex-plane length (pidx(1024) = 1088 fits)
 
+template <int FPB>
 __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict__ pcm, size_t total_bytes,
                                                        size_t stride_bytes, int n_windows, FrontendTables T,
                                                        float *__restrict__ melT /*[n_windows][188][128]*/)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict
     if (tid < kNmels) { s_start[tid] = T.mel_start[tid]; s_len[tid] = T.mel_len[tid]; s_off[tid] = T.mel_off[tid]; }
     __syncthreads();
 
-    const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
+    const int groups = (T.n_frames + FPB - 1) / FPB;
     const int win = blockIdx.x / groups, fg = blockIdx.x % groups;
     if (win >= n_windows) return;
     float *re = s_re[wave], *im = s_im[wave];
@@ -132,8 +133,8 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(maxlen, o); maxlen = t > maxlen ? t : maxlen; }
 
-    for (int it = 0; it < kFramesPerBlock / 4; it++) {
-        const int frame = fg * kFramesPerBlock + it * 4 + wave;
+    for (int it = 0; it < FPB / 4; it++) {
+        const int frame = fg * FPB + it * 4 + wave;
         if (frame >= T.n_frames) break;   // wave-uniform
         const long s_begin = (long)T.frame_origin + (long)frame * kHop;   // first sample of the frame
 
@@ -279,7 +280,9 @@ __global__ __launch_bounds__(256) void db_norm_kernel(const float *__restrict__ 
     const float amin = 1e-10f;
     const float ref_db = 10.0f * log10f(fmaxf(mx, amin));         // librosa: 10*log10(max(amin, ref))
     // librosa top_db: log_spec.max() - 80 with log_spec.max() = 10*log10(max(amin,mx)) - ref_db = 0
-    for (int t0 = 0; t0 < kSpecFrames; t0 += 32) {
+    // gridDim.y == 1: this block walks all six 32-frame column chunks; gridDim.y == 6 (single clips): one each
+    const int t_step = 32 * (int)gridDim.y;
+    for (int t0 = 32 * (int)blockIdx.y; t0 < kSpecFrames; t0 += t_step) {
         __syncthreads();
         // load 32 frames x 128 bands, convert, stage transposed
 #pragma unroll

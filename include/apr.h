@@ -68,7 +68,13 @@ const char *apr_version(void);
  *                   blob (apr_amd/weights.py).  NULL/0 creates a
  *                   front-end-only engine (enough for Prepare).
  *   max_batch     : windows processed per GPU pass (activation buffers are
- *                   sized for it); <=0 picks the default (1024).
+ *                   sized for it); <=0 picks the default (1024).  max_batch <= 4
+ *                   makes a latency engine for the daemon's one-clip-per-Infer
+ *                   pattern (src/daemon/daemon.go:132-136): the layers whose grid
+ *                   is a handful of tiles run split along K.  Its results agree
+ *                   with a throughput engine's to fp32 rounding (another summation
+ *                   order), not bit for bit; all throughput engines agree bit for
+ *                   bit with each other whatever their max_batch.
  * Replaces the per-call `gorgonnx.NewGraph()` + `UnmarshalBinary` of
  * src/model/model.go:190-196: parsing and upload happen once, here.
  */

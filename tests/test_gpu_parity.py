@@ -256,7 +256,7 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
     default = run({})
     unfused = run({"APR_WINO_FUSED": "0", "APR_WINO_MIN_CIN": "64"})    # every stride-1 igemm layer, three-kernel form
     fused = run({"APR_WINO_FUSED_MAX_CIN": "512"})                      # every stride-1 igemm layer, one-kernel form
-    fused1 = run({"APR_WINO_FUSED_MAX_CIN": "512"}, batch=1)            # ragged tile blocks (6 windows in chunks of 1)
+    fused1 = run({"APR_WINO_FUSED_MAX_CIN": "512", "APR_SPLITK": "0"}, batch=1)   # ragged tile blocks (6 windows in chunks of 1)
     for got in (direct, default, unfused, fused, fused1):
         assert np.abs(got - want).max() <= LOGIT_TOL
     for got in (default, unfused, fused):
@@ -288,3 +288,21 @@ def test_sweep_files_equals_per_file_score(he_weights):
     assert np.array_equal(again["probs"], got["probs"][:7])
     assert eng.sweep_files([], trust=0.4)["label"].shape == (0,)
     eng.close()
+
+
+def test_latency_engine_split_k(he_weights):
+    # max_batch <= 4 (one clip per call, the daemon's pattern): the direct layers run split along K.  Same
+    # arithmetic in another summation order: inside the logit tolerance, labels equal, not bit-equal.
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
+    blob = W.pack_blob(he_weights, 4)
+    lat = model.Engine(blob, 0, 1)
+    thr = model.Engine(blob, 0, 8)
+    a, b = lat.infer_logits(specs), thr.infer_logits(specs)
+    assert np.abs(a - want).max() <= LOGIT_TOL
+    assert np.abs(a - b).max() <= 2e-5 and not np.array_equal(a, b)
+    assert np.array_equal(lat.infer_logits(specs), a)                 # deterministic: splits are added in index order
+    pcm = model.synth_pcm(7, 0, 6)
+    ra, rb = lat.score(pcm, 5, trust=0.3, empty_class=2), thr.score(pcm, 5, trust=0.3, empty_class=2)
+    assert np.array_equal(ra["label"], rb["label"]) and np.abs(ra["probs"] - rb["probs"]).max() <= 1e-5
+    lat.close(); thr.close()
