@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapr_amd.so")
+LIB_PATH = os.environ.get("APR_AMD_LIB") or os.path.join(_HERE, "libapr_amd.so")   # APR_AMD_LIB: developer builds
 
 APR_OK = 0
 ERR_INVALID, ERR_DEVICE, ERR_MODEL, ERR_NOMEM, ERR_NOMODEL = -1, -2, -3, -4, -5

@@ -397,19 +397,14 @@ int run_frontend(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_
                  float *d_out)
 {
     const FrontendTables &T = e->tab[flavour];
-    // a handful of windows (live clips): one frame per wave and one column chunk per block, so that the
-    // front end's latency is one frame's, not four; the arithmetic per frame / element is the same code
+    const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
+    // a handful of windows (live clips): db_norm gets one block per 32-frame column chunk instead of one per
+    // window, so its latency is a sixth; the arithmetic per element is the same code
     const bool few = n_windows <= 8;
-    const int fpb = few ? 4 : kFramesPerBlock;
-    const int groups = (T.n_frames + fpb - 1) / fpb;
     {
         ProfScope ps(e, 0, (double)n_windows * T.n_frames * 5.0 * kNfft * 11.0 + 2.0 * T.nnz * T.n_frames * n_windows,
                      (double)n_windows * (std::min<size_t>(stride, APR_SAMPLE_SIZE) + (double)T.n_frames * kNmels * 4));
-        if (few)
-            hipLaunchKernelGGL(stft_mel_kernel<4>, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, e->d_melT);
-        else
-            hipLaunchKernelGGL(stft_mel_kernel<kFramesPerBlock>, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride,
-                               n_windows, T, e->d_melT);
+        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, e->d_melT);
     }
     {
         ProfScope ps(e, 1, 0.0, (double)n_windows * ((double)T.n_frames * kNmels * 4 + APR_SPEC_ELEMS * 4));

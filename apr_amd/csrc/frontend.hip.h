@@ -23,7 +23,8 @@ constexpr int kHop = 512;
 constexpr int kNmels = 128;
 constexpr int kSpecFrames = 188;
 constexpr int kSampleBytes = 192000;
-constexpr int kFramesPerBlock = 16;   // 4 waves x 4 frames (throughput); 4 = one frame per wave for single clips
+constexpr int kFramesPerBlock = 4;    // one frame per wave: 90 VGPRs, 3 workgroups per CU (LDS-bound).  Four frames per wave
+                                      // let hipcc keep window + twiddles in registers (246 VGPRs, 2 waves/SIMD) and ran 24 % slower.
 constexpr int kMaxNnz = 2304;         // CSR capacity (go lens: 1892, librosa: ~2.1k)
 
 struct FrontendTables {
@@ -96,7 +97,6 @@ __device__ __forceinline__ void wave_lds_sync()
 
 constexpr int kLdsWave = 1104;   // padded complex-plane length (pidx(1024) = 1088 fits)
 
-template <int FPB>
 __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict__ pcm, size_t total_bytes,
                                                        size_t stride_bytes, int n_windows, FrontendTables T,
                                                        float *__restrict__ melT /*[n_windows][188][128]*/)
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict
     if (tid < kNmels) { s_start[tid] = T.mel_start[tid]; s_len[tid] = T.mel_len[tid]; s_off[tid] = T.mel_off[tid]; }
     __syncthreads();
 
+    constexpr int FPB = kFramesPerBlock;
     const int groups = (T.n_frames + FPB - 1) / FPB;
     const int win = blockIdx.x / groups, fg = blockIdx.x % groups;
     if (win >= n_windows) return;
