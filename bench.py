@@ -200,7 +200,7 @@ def main() -> int:
         out["p99_clip_latency_ms"] = float(np.percentile(lat[5:], 99))
 
     # ---- CPU baseline: the oracle (port of the reference CPU path) on a bounded sample ----
-    if args.cpu_windows > 0 and not args.no_extras:
+    if args.cpu_windows > 0 and not args.no_extras and world == 1:   # rank 0 at N = 1 only
         import oracle   # test infrastructure; used here only as the timed CPU stand-in / checker
         nw = min(args.cpu_windows, args.seconds - 1)
         sample = pcm_host[: (nw + 1) * 48000]
