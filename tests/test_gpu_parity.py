@@ -306,3 +306,48 @@ def test_latency_engine_split_k(he_weights):
     ra, rb = lat.score(pcm, 5, trust=0.3, empty_class=2), thr.score(pcm, 5, trust=0.3, empty_class=2)
     assert np.array_equal(ra["label"], rb["label"]) and np.abs(ra["probs"] - rb["probs"]).max() <= 1e-5
     lat.close(); thr.close()
+
+
+def test_full_size_sweep_properties(he_weights):
+    # BASELINE config 2 at full size (60 recordings x 600 s = 35 999 stream windows on one GPU),
+    # checked through size-independent properties + an oracle sample.
+    C, empty, trust = 4, 2, 0.5
+    secs, n_files = 600, 60
+    # classifier bias centred as in bench.py so that all four labels occur
+    e0 = model.Engine(W.pack_blob(he_weights, C), 0, 64)
+    first = model.synth_pcm(0, 0, 65)
+    flat = W.center_logits(he_weights, C, e0.infer_logits(e0.prepare_batch(first, 64)).mean(axis=0))
+    e0.close()
+    half = np.concatenate([model.synth_pcm(0, f, secs) for f in range(n_files // 2)])
+    pcm = np.concatenate([half, half])                       # recordings 30..59 repeat recordings 0..29
+    plan = sweep.plan_stream([secs * 96000] * n_files)
+    n = plan.n_windows
+    assert n == 35999 and plan.n_valid == 35940
+    eng = model.Engine(W.pack_blob(flat, C), 0, 1024)
+    runs = []
+    for _ in range(2):
+        r = eng.score(pcm, n, trust=trust, empty_class=empty)     # host pointers: 36 passes of 1024 windows
+        runs.append((r["probs"], r["label"], r["match"]))
+    probs, label, match = runs[0]
+    assert all(np.array_equal(a, b) for a, b in zip(runs[0], runs[1]))              # deterministic
+    assert np.isfinite(probs).all() and probs.min() >= 0.0 and np.abs(probs.sum(axis=1) - 1.0).max() < 1e-12
+    assert np.array_equal(label, probs.argmax(axis=1))                              # daemon.go:193-198
+    conf = probs[np.arange(n), label]
+    assert np.array_equal(match.astype(bool), (label != empty) & (conf > trust))    # daemon.go:203
+    assert len(np.unique(label[plan.valid])) == C                                   # every class occurs
+    # translation: a recording scored 18 000 windows later (other chunk, other position in it) gives the same bits
+    h = (n_files // 2) * secs
+    va = plan.valid[:h - 1]
+    assert np.array_equal(probs[:h - 1][va], probs[h:2 * h - 1][va]) and np.array_equal(label[:h - 1][va], label[h:2 * h - 1][va])
+    # oracle on a sample spread over the sweep
+    ks = [k for k in np.linspace(0, n - 1, 24).astype(int) if plan.valid[k]]
+    for k in ks:
+        ref = oracle.score(flat, C, pcm[k * 48000:(k + 2) * 48000], 1, trust=trust, empty_class=empty)
+        assert np.abs(ref["probs"][0] - probs[k]).max() <= 1e-4
+        srt = np.sort(ref["logits"][0])
+        if srt[-1] - srt[-2] > 4e-4:
+            assert ref["label"][0] == label[k] and ref["match"][0] == match[k]
+    # timestamps as ai/inspect.py prints them: window k of file f is second k+1
+    lines = sweep.format_matches("m", LABELS, {f: f"rec{f}.mkv" for f in range(n_files)}, plan, label, match)
+    assert len(lines) == int((match.astype(bool) & plan.valid).sum())
+    eng.close()
