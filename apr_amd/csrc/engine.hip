@@ -459,7 +459,7 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             const long long tiles_m = (T + WF_TT - 1) / WF_TT;
             ProfScope ps(e, L.slot, 2.0 * 16.0 * (double)T * L.cin * L.cout, bytes + 4.0 * 7.0 * L.cin * L.cout);
             hipLaunchKernelGGL(wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
-                               out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n);
+                               out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
             in = out;
             continue;
         }

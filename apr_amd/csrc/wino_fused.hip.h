@@ -76,11 +76,28 @@ constexpr int WF_LDS_BYTES = 2 * 2 * WF_POS * 4 + WF_TT * 8;
 #define APR_WF_CLUMP 1
 #endif
 
+#ifdef APR_WF_STAMPS   // developer build (tools/wino_fused_bench.cpp): s_memtime stamps of the first blocks
+__device__ unsigned long long wf_stamps[4096][8];
+#define WF_STAMP(I_) if (blockIdx.x < 4096 && threadIdx.x == 0) wf_stamps[blockIdx.x][I_] = __builtin_amdgcn_s_memtime();
+#else
+#define WF_STAMP(I_)
+#endif
+
+// Division by the launch's small constants without the ~30-instruction expansion per quotient:
+// q = (n * ceil(2^40 / d)) >> 40, exact while q < 2^24 and n < 2^31 (host: wf_magic).
+struct WfMagic { unsigned long long tiles_n, tpw, tw, th; };
+__device__ __forceinline__ int wf_div(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
+inline WfMagic wf_magic(int tiles_n, int th, int tw)
+{
+    auto mk = [](long long d) { return (unsigned long long)(((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d); };
+    return WfMagic{mk(tiles_n), mk((long long)th * tw), mk(tw), mk(th)};
+}
+
 // in  [B][H][W][Cin] ; up = packed U (wf_pack_u) ; out [B][H][W][Cout] = relu(conv + bias)
 // T = B * th * tw tiles, th = ceil(H/2), tw = ceil(W/2).  Requires Cin % 16 == 0, Cout % 64 == 0.
 __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ in, const float *__restrict__ up,
                                                      const float *__restrict__ bias, float *__restrict__ out, int H,
-                                                     int W, int Cin, int Cout, int th, int tw, int T, int tiles_n)
+                                                     int W, int Cin, int Cout, int th, int tw, int T, int tiles_n, WfMagic mg)
 {
     extern __shared__ __attribute__((aligned(16))) float wf_smem[];
     float *Vs = wf_smem;                        // [2][WF_POS]
@@ -90,17 +107,20 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, half = lane >> 5;
+    WF_STAMP(0)
+#ifdef APR_WF_STAMPS
+    if (blockIdx.x < 4096 && threadIdx.x == 0) wf_stamps[blockIdx.x][6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+#endif
 
     // XCD-aware block order (see conv3x3_igemm_f32)
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int bn = lid % tiles_n;
-    const int bm = lid / tiles_n;
+    const int bm = wf_div(lid, mg.tiles_n);
+    const int bn = lid - bm * tiles_n;
 
-    const int tpw = th * tw;                     // tiles per window
     const int g0 = bm * WF_TT;                   // first tile of the block (< T)
-    const int b0 = g0 / tpw;                     // its window
+    const int b0 = wf_div(g0, mg.tpw);           // its window
 
     // ---- input patch addressing: buffer loads, zero padding through out-of-range offsets ----
     constexpr unsigned OOB = 0x80000000u;
@@ -112,19 +132,20 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
         int tpx = -1, tfl = 0;                   // the tile's entry of the epilogue's table, from the same divisions
         const int g = g0 + t_ld;
         if (g < T) {
-            const int tx = g % tw;
-            const int rr = g / tw;
-            const int ty = rr % th;
-            const int db = rr / th - b0;
+            const int rr = wf_div(g, mg.tw);
+            const int tx = g - rr * tw;
+            const int bb = wf_div(rr, mg.th);
+            const int ty = rr - bb * th;
+            const int db = bb - b0;
             const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
             voff = 4u * (unsigned)(((db * H + y0 + 1) * W + x0 + 1) * Cin + 2 * cp);
             tpx = (db * H + 2 * ty) * W + 2 * tx;   // relative to the block's first window
             tfl = (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0);
+            // patch rows 2ty-1 .. 2ty+2 and columns 2tx-1 .. 2tx+2 inside the image (rows/columns 1 always are)
+            const unsigned rowok = (ty > 0 ? 1u : 0u) | 2u | (2 * ty + 1 < H ? 4u : 0u) | (2 * ty + 2 < H ? 8u : 0u);
+            const unsigned colok = (tx > 0 ? 1u : 0u) | 2u | (2 * tx + 1 < W ? 4u : 0u) | (2 * tx + 2 < W ? 8u : 0u);
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (y0 + i >= 0 && y0 + i < H && x0 + j >= 0 && x0 + j < W) vmask |= 1u << (4 * i + j);
+            for (int i = 0; i < 4; i++) vmask |= ((rowok >> i) & 1u) ? colok << (4 * i) : 0u;
         }
         if (cp == 0) {
             tbl[2 * t_ld] = tpx;
@@ -189,10 +210,6 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
     const int rd_u = (wn * 32 + li) * WF_BK + rd_sw;
 
     f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; p++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[p][e] = 0.0f;
 
     f32x4 af[2][2], bf[2][2];
     // one operand (Q_ = 0: A of position 2G, 1: B of 2G, 2: A of 2G+1, 3: B of 2G+1) from LDS buffer BUF_ into set SET_
@@ -204,11 +221,19 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
             bf[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(Us + (BUF_) * WF_POS + rd_u + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)); \
     }
 
+    WF_STAMP(1)
     WF_DMA_U(0, 0)
 #pragma unroll
     for (int ij = 0; ij < 16; ij++) WF_LOAD_V1(dB, 0, ij)
 #pragma unroll
     for (int ij = 0; ij < 16; ij++) WF_LOAD_V1(dA, (KC > 1 ? 1 : 0), ij)
+    // clearing the 256 accumulators is 1k cycles of VALU: here, under the latency of the first loads
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 16; p++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[p][e] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; j++) { WF_ROWS_HALF(dB, j, 0) WF_ROWS_HALF(dB, j, 1) }
 #pragma unroll
@@ -221,8 +246,9 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) WF_STORE_POS(dB, 1, i, qq)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the DMA and V(0) have landed; the 16 loads of V(1) may still fly
     __syncthreads();
 #pragma unroll
     for (int qq = 0; qq < 4; qq++) WF_READ_OP(0, 0, 0, qq)
@@ -273,6 +299,7 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
         cur ^= 1;                                                                                        \
     }
 
+    WF_STAMP(2)
     int cur = 0;
     for (int kc = 0; kc < KC; kc += 2) {   // KC is even (Cin % 16 == 0, host-checked)
         WF_KSTEP(dA, dB)
@@ -281,6 +308,7 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
         kc--;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads / DMA land before the block ends
+    WF_STAMP(3)
 #undef WF_KSTEP
 #undef WF_READ_OP
 #undef WF_LOAD_V1
@@ -318,6 +346,11 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
         wf_store1(rsO, px >= 0 && (fl & 1) ? o0 + 4u * (unsigned)(W * Cout) : OOB, y10);
         wf_store1(rsO, px >= 0 && (fl & 3) == 3 ? o0 + 4u * (unsigned)((W + 1) * Cout) : OOB, y11);
     }
+    WF_STAMP(4)
+#ifdef APR_WF_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    WF_STAMP(5)
 }
 
 // Host: g [Cout][Cin][3][3] (OIHW, BN folded) -> packed U for wino_fused_f2:

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -68,7 +69,7 @@ int main(int argc, char **argv)
     const int tiles_n = Cout / apr::WF_BN;
     const long long tiles_m = (T + apr::WF_TT - 1) / apr::WF_TT;
     auto launch = [&]() {
-        hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n);
+        hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw));
     };
     launch();
     CK(hipGetLastError());
@@ -90,6 +91,30 @@ int main(int argc, char **argv)
     const double flx = 2.0 * 16.0 * (double)T * Cin * Cout;
     printf("%dx%d Cin=%d Cout=%d B=%d: %.3f ms  effective %.1f TFLOP/s  executed %.1f TFLOP/s  blocks=%lld  max|diff|=%.3e (max|ref|=%.3e)\n", H, W, Cin,
            Cout, B, ms, fl / ms / 1e9, flx / ms / 1e9, tiles_m * tiles_n, stat[0], stat[1]);
+#ifdef APR_WF_STAMPS
+    {
+        // per-block phase times (s_memtime ticks at 100 MHz on this chip? printed raw) and the gap between
+        // consecutive blocks on the same CU (HW_ID: cu_id, sh_id, se_id; xcc via XCC_ID not read -> group by bid&7 too)
+        static unsigned long long h[4096][8];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(apr::wf_stamps), sizeof h));
+        const int nb = (int)std::min<long long>(4096, tiles_m * tiles_n);
+        double ph[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nb; b++) for (int i = 0; i < 5; i++) ph[i] += (double)(h[b][i + 1] - h[b][i]);
+        printf("stamps (avg ticks over %d blocks): setup %.0f  first-loads+transform+barrier %.0f  K loop %.0f  epilogue issue %.0f  store drain %.0f\n", nb,
+               ph[0] / nb, ph[1] / nb, ph[2] / nb, ph[3] / nb, ph[4] / nb);
+        // gap: for every CU slot (xcd = b&7, hw_id), sort by start and take next.start - prev.end
+        std::vector<std::pair<unsigned long long, int>> order;
+        double gap = 0; int ng = 0;
+        for (int b = 0; b < nb; b++) {
+            unsigned long long best = ~0ull; int bi = -1;
+            for (int c = 0; c < nb; c++)
+                if (c != b && (c & 7) == (b & 7) && h[c][6] == h[b][6] && h[c][0] >= h[b][5] && h[c][0] < best) { best = h[c][0]; bi = c; }
+            if (bi >= 0) { gap += (double)(best - h[b][5]); ng++; }
+        }
+        printf("gap between a block's end and the next block's first instruction on the same CU: %.0f ticks (%d pairs)\n", ng ? gap / ng : 0.0, ng);
+        printf("block 0: %llu %llu %llu %llu %llu %llu hwid %llx\n", h[0][0], h[0][1] - h[0][0], h[0][2] - h[0][0], h[0][3] - h[0][0], h[0][4] - h[0][0], h[0][5] - h[0][0], h[0][6]);
+    }
+#endif
     if (argc > 7) return 0;   // timing-only ablation builds
     return std::isfinite(stat[0]) && stat[0] <= 1e-4f * fmaxf(stat[1], 1.0f) ? 0 : 2;
 }
