@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void wino_fused_f2(const float *__restrict__ i
 #pragma unroll
     for (int ij = 0; ij < 16; ij++)
         vo[ij] = ((vmask >> ij) & 1u) ? voff + 4u * (unsigned)(((ij >> 2) * W + (ij & 3)) * Cin) : OOB;
-#define WF_LOAD_V1(D_, KC_, IJ_) D_[IJ_] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, vo[IJ_], 4 * (KC_) * WF_BK, 0));
+#define WF_LOAD_V1(D_, KC_, IJ_) D_[IJ_] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, APR_WF_EXP_LOADV == 2 ? (vo[IJ_] | OOB) : vo[IJ_], 4 * (KC_) * WF_BK, 0));
 #define WF_DMA_U1(KC_, BUF_, I_) lds_dma_b128(rsU, uvoff, (KC_) * (WF_POS * 4) + (I_) * 1024, us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024));
 #define WF_DMA_U(KC_, BUF_)                                                                              \
     {                                                                                                    \
