@@ -19,6 +19,7 @@
 #include "model_parse.h"
 #include "wino.hip.h"
 #include "wino_fused.hip.h"
+#include "wino_fused8.hip.h"
 
 using namespace apr;
 
@@ -32,7 +33,8 @@ struct Layer {
     float *d_b = nullptr;   // [cout]
     int bn_tile = 0, bm_tile = 128;
     // Winograd F(2x2,3x3) path (stride-1 layers with enough channels to amortise the transforms)
-    int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3)
+    int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2)
+    int fused_waves = 8;    // wino == 3: wino_fused8_f2 (8 waves a block) or wino_fused_f2 (4)
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
     int th = 0, tw = 0;     // 2x2-output tiles per window
     int wbm_tile = 128;
@@ -302,7 +304,9 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             std::vector<float> u((size_t)16 * cv.cin * cv.cout);
             wf_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+            const char *wv = getenv("APR_WINO_FUSED_WAVES");   // developer knob: 4 = the four-wave kernel
             L.wino = 3;
+            L.fused_waves = wv && atoi(wv) == 4 ? 4 : 8;
             L.ksplit = 1;
             L.th = (L.hout + 1) / 2;
             L.tw = (L.wout + 1) / 2;
@@ -458,8 +462,12 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             const int tiles_n = L.cout / WF_BN;
             const long long tiles_m = (T + WF_TT - 1) / WF_TT;
             ProfScope ps(e, L.slot, 2.0 * 16.0 * (double)T * L.cin * L.cout, bytes + 4.0 * 7.0 * L.cin * L.cout);
-            hipLaunchKernelGGL(wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
-                               out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
+            if (L.fused_waves == 4)
+                hipLaunchKernelGGL(wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
+                                   out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
+            else
+                hipLaunchKernelGGL(wino_fused8_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
+                                   out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
             in = out;
             continue;
         }
@@ -614,7 +622,8 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         e->err = "could not create a stream on the device";
         rc = APR_ERR_DEVICE;
     }
-    if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES) != hipSuccess) {
+    if (!rc && (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused8_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES) != hipSuccess)) {
         e->err = "could not reserve LDS for wino_fused_f2";
         rc = APR_ERR_DEVICE;
     }
@@ -624,7 +633,7 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         for (size_t l = 0; l < e->layers.size(); l++) {
             Layer &L = e->layers[l];
             char nm[48];
-            if (L.wino == 3) snprintf(nm, sizeof nm, "wino_fused_f2");
+            if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
             else if (L.wino) {
                 L.slot_in = e->n_slots;
                 add_slot(e, "wino_input_f2", (int)l + 1);

@@ -1,0 +1,265 @@
+// wino_fused8.hip.h -- wino_fused_f2 with TWO waves per SIMD.
+//
+// Same work unit (64 tiles x 64 channels, 16 transform positions, K step = 8 input channels, same
+// LDS images) as wino_fused.hip.h, but 8 waves per workgroup: the two waves of a pair own the same
+// 32 tiles x 32 channels and split the 16 positions 8 / 8 -- 128 accumulator registers each, so two
+// waves fit on a SIMD (256 registers per lane each) and one wave's LDS / barrier / memory waits are
+// filled by the other's MFMAs.  The staging work alternates between the halves: in every K step
+// the waves of one parity issue the patch loads of chunk k+2 while the waves of the other parity
+// transform and store chunk k+1 and DMA its U image (one register set per wave, no wave ever has
+// loads and a DMA in flight together, so every vmcnt wait is exact).
+// Epilogue: the output transform is linear in the positions, so each wave reduces its 8 positions
+// to partial 2x2 outputs, the pair swaps halves through LDS (the idle Vs buffers) and each wave
+// finishes and stores two of the four pixels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wino_fused.hip.h"
+
+namespace apr {
+
+__global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ in, const float *__restrict__ up,
+                                                      const float *__restrict__ bias, float *__restrict__ out, int H,
+                                                      int W, int Cin, int Cout, int th, int tw, int T, int tiles_n, WfMagic mg)
+{
+    extern __shared__ __attribute__((aligned(16))) float wf_smem[];
+    float *Vs = wf_smem;                        // [2][WF_POS]; after the K loop: the pairs' exchange buffers
+    float *Us = wf_smem + 2 * WF_POS;           // [2][WF_POS]
+    int *tbl = reinterpret_cast<int *>(wf_smem + 4 * WF_POS);   // [64][2]: output pixel of (b, 2ty, 2tx) or -1; flags
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ph = wave & 1;                    // which 8 of the 16 positions; also the staging parity
+    const int sub = wave >> 1;                  // the pair: 2 (tiles) x 2 (channels)
+    const int wm = sub >> 1, wn = sub & 1;
+    const int li = lane & 31, half = lane >> 5;
+    const int sid = sub * 64 + lane;            // 0..255 among the four waves of one parity
+    WF_STAMP(0)
+
+    // XCD-aware block order (see conv3x3_igemm_f32)
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int bm = wf_div(lid, mg.tiles_n);
+    const int bn = lid - bm * tiles_n;
+    const int g0 = bm * WF_TT;                   // first tile of the block (< T)
+    const int b0 = wf_div(g0, mg.tpw);           // its window
+
+    // ---- input patch addressing (every parity stages whole chunks: 256 threads = 64 tiles x 4 channel pairs) ----
+    constexpr unsigned OOB = 0x80000000u;
+    const float *abase = in + (((long long)b0 * H - 1) * W - 1) * (long long)Cin;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x40000000, 0x00020000);
+    const int t_ld = sid >> 2, cp = sid & 3;
+    unsigned voff = OOB, vmask = 0;
+    {
+        int tpx = -1, tfl = 0;
+        const int g = g0 + t_ld;
+        if (g < T) {
+            const int rr = wf_div(g, mg.tw);
+            const int tx = g - rr * tw;
+            const int bb = wf_div(rr, mg.th);
+            const int ty = rr - bb * th;
+            const int db = bb - b0;
+            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+            voff = 4u * (unsigned)(((db * H + y0 + 1) * W + x0 + 1) * Cin + 2 * cp);
+            tpx = (db * H + 2 * ty) * W + 2 * tx;
+            tfl = (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0);
+            const unsigned rowok = (ty > 0 ? 1u : 0u) | 2u | (2 * ty + 1 < H ? 4u : 0u) | (2 * ty + 2 < H ? 8u : 0u);
+            const unsigned colok = (tx > 0 ? 1u : 0u) | 2u | (2 * tx + 1 < W ? 4u : 0u) | (2 * tx + 2 < W ? 8u : 0u);
+#pragma unroll
+            for (int i = 0; i < 4; i++) vmask |= ((rowok >> i) & 1u) ? colok << (4 * i) : 0u;
+        }
+        if (cp == 0 && ph == 0) {
+            tbl[2 * t_ld] = tpx;
+            tbl[2 * t_ld + 1] = tfl;
+        }
+    }
+    const int KC = Cin / WF_BK;
+    const unsigned long long ub = (unsigned long long)(up + (size_t)bn * KC * WF_POS);
+    i32x4 rsU;
+    rsU.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub);
+    rsU.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32) & 0xFFFF);
+    rsU.z = 0x7FFFFFFF;
+    rsU.w = 0x00020000;
+    const unsigned us_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(Us + sub * (WF_POS / 4)));
+    const unsigned uvoff = (unsigned)(sub * (WF_POS / 4) * 4 + lane * 16);
+
+    f32x2 d[16];
+    unsigned vo[16];
+#pragma unroll
+    for (int ij = 0; ij < 16; ij++)
+        vo[ij] = ((vmask >> ij) & 1u) ? voff + 4u * (unsigned)(((ij >> 2) * W + (ij & 3)) * Cin) : OOB;
+#define W8_LOAD_V1(KC_, IJ_) d[IJ_] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, vo[IJ_], 4 * (KC_) * WF_BK, 0));
+#define W8_DMA_U1(KC_, BUF_, I_) lds_dma_b128(rsU, uvoff, (KC_) * (WF_POS * 4) + (I_) * 1024, us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024));
+#define W8_ROWS()                                                                                        \
+    {                                                                                                    \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                                                 \
+        {                                                                                                \
+            const f32x2 r0_ = wf_sub2(d[j_], d[8 + j_]), r3_ = wf_sub2(d[4 + j_], d[12 + j_]);           \
+            const f32x2 r1_ = wf_add2(d[4 + j_], d[8 + j_]), r2_ = wf_sub2(d[8 + j_], d[4 + j_]);        \
+            d[j_] = r0_; d[4 + j_] = r1_; d[8 + j_] = r2_; d[12 + j_] = r3_;                             \
+        }                                                                                                \
+    }
+#define W8_STORE_POS(BUF_, I_, Q_)                                                                       \
+    {                                                                                                    \
+        const f32x2 v_ = (Q_) == 0   ? wf_sub2(d[4 * (I_)], d[4 * (I_) + 2])                             \
+                         : (Q_) == 1 ? wf_add2(d[4 * (I_) + 1], d[4 * (I_) + 2])                         \
+                         : (Q_) == 2 ? wf_sub2(d[4 * (I_) + 2], d[4 * (I_) + 1])                         \
+                                     : wf_sub2(d[4 * (I_) + 1], d[4 * (I_) + 3]);                        \
+        *reinterpret_cast<f32x2 *>(Vs + (BUF_) * WF_POS + (4 * (I_) + (Q_)) * (64 * WF_BK) + st_off) = v_; \
+    }
+    const int st_off = t_ld * WF_BK + (((cp >> 1) ^ ((t_ld >> 4) & 1)) * 4) + (cp & 1) * 2;
+    const int rd_sw = (half ^ ((li >> 4) & 1)) * 4;
+    const int rd_v = (ph * 8) * (64 * WF_BK) + (wm * 32 + li) * WF_BK + rd_sw;   // this wave's first position
+    const int rd_u = (ph * 8) * (64 * WF_BK) + (wn * 32 + li) * WF_BK + rd_sw;
+
+    f32x16 acc[8];
+    f32x4 af[2][2], bf[2][2];
+#define W8_READ_OP(SET_, BUF_, G_, Q_)                                                                   \
+    {                                                                                                    \
+        if (((Q_) & 1) == 0)                                                                             \
+            af[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(Vs + (BUF_) * WF_POS + rd_v + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)); \
+        else                                                                                             \
+            bf[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(Us + (BUF_) * WF_POS + rd_u + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)); \
+    }
+
+    // ---- prologue: parity 0 stages chunk 0, parity 1 loads chunk 1 ----
+    WF_STAMP(1)
+    if (ph == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) W8_DMA_U1(0, 0, i)
+    }
+    {
+        const int c_ = ph;   // KC >= 2
+#pragma unroll
+        for (int ij = 0; ij < 16; ij++) W8_LOAD_V1(c_, ij)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[p][e] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    if (ph == 0) {
+        W8_ROWS()
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) W8_READ_OP(0, 0, 0, qq)
+
+    // K step: 32 slots of one MFMA (4 groups g of two positions x 4 k-pairs), each closed by a full
+    // scheduling barrier.  Slots 0-3 of a group read the next group's operands (g = 3: after the
+    // barrier, the next step's first group).
+    //   ROLE 0 (load):   chunk kc+2 -> d, one buffer load per slot in groups 0-1
+    //   ROLE 1 (store):  slot 0 row transform of d (chunk kc+1, loaded in the previous step); groups 0-1 the
+    //                    U(kc+1) DMA, one piece per slot from slot 1; groups 1-2 the column transform + LDS
+    //                    store, one row (four positions) per fourth slot; before the barrier vmcnt(0)
+    // Chunk indices past the end are clamped (staging nobody reads).
+#define W8_KSTEP(ROLE)                                                                                   \
+    {                                                                                                    \
+        const int kn1 = kc + 1 < KC ? kc + 1 : KC - 1;                                                   \
+        const int kn2 = kc + 2 < KC ? kc + 2 : KC - 1;                                                   \
+        _Pragma("unroll") for (int g = 0; g < 4; g++)                                                    \
+        {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 8; i++)                                                \
+            {                                                                                            \
+                const int sl = 8 * g + i;                                                                \
+                if (g == 3 && i == 0) {                                                                  \
+                    if (ROLE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
+                    __syncthreads();                                                                     \
+                }                                                                                        \
+                if (i < 4) {                                                                             \
+                    if (g < 3) W8_READ_OP((g + 1) & 1, cur, g + 1, i)                                    \
+                    else W8_READ_OP(0, cur ^ 1, 0, i)                                                    \
+                }                                                                                        \
+                if (ROLE == 0 && sl < 16) W8_LOAD_V1(kn2, sl)                                            \
+                if (ROLE == 1 && sl == 0) W8_ROWS()                                                      \
+                if (ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(kn1, cur ^ 1, sl - 1)                     \
+                if (ROLE == 1 && sl >= 10 && sl <= 22 && ((sl - 10) & 3) == 0) {                         \
+                    _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) W8_STORE_POS(cur ^ 1, (sl - 10) >> 2, q_) \
+                }                                                                                        \
+                acc[2 * g + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i & 1][i >> 1], bf[g & 1][i & 1][i >> 1], acc[2 * g + (i & 1)], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                                       \
+            }                                                                                            \
+        }                                                                                                \
+        cur ^= 1;                                                                                        \
+    }
+
+    WF_STAMP(2)
+    int cur = 0;
+    if (ph == 0) {
+        for (int kc = 0; kc < KC; kc += 2) {   // KC is even
+            W8_KSTEP(0)
+            kc++;
+            W8_KSTEP(1)
+            kc--;
+        }
+    } else {
+        for (int kc = 0; kc < KC; kc += 2) {
+            W8_KSTEP(1)
+            kc++;
+            W8_KSTEP(0)
+            kc--;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WF_STAMP(3)
+#undef W8_KSTEP
+#undef W8_READ_OP
+#undef W8_LOAD_V1
+#undef W8_DMA_U1
+#undef W8_ROWS
+#undef W8_STORE_POS
+
+    // ---- epilogue.  acc[q][e]: position ph*8 + q = row 2 ph + q/4, column q%4 of the 4x4 m; e -> tile row
+    //      (e&3) + 8*(e>>2) + 4*(lane>>5), lane&31 -> channel.  A^T = [1 1 1 0; 0 1 -1 -1].
+    //      partial outputs of this wave's two m rows; the pair swaps halves through LDS:
+    //      parity 0 finishes pixels (0,0),(0,1), parity 1 finishes (1,0),(1,1) ----
+    float *xw = Vs + ((sub * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [e][lane][2]
+    const float *xr = Vs + ((sub * 2 + (ph ^ 1)) * 16) * 128 + lane * 2;   // what it receives
+    float keep[16][2];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (ph == 0) { t0[j] = acc[j][e] + acc[4 + j][e]; t1[j] = acc[4 + j][e]; }
+            else { t0[j] = acc[j][e]; t1[j] = -acc[j][e] - acc[4 + j][e]; }
+        }
+        const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
+        const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
+        f32x2 give;
+        if (ph == 0) { keep[e][0] = y00; keep[e][1] = y01; give.x = y10; give.y = y11; }
+        else { keep[e][0] = y10; keep[e][1] = y11; give.x = y00; give.y = y01; }
+        *reinterpret_cast<f32x2 *>(xw + e * 128) = give;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    const int n = bn * WF_BN + wn * 32 + li;
+    const float bv = bias[n];
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
+    const unsigned nb4 = 4u * (unsigned)n;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const int px = tbl[2 * tl], fl = tbl[2 * tl + 1];
+        const f32x2 got = *reinterpret_cast<const f32x2 *>(xr + e * 128);
+        // parity 0 adds the partner's rows 2,3 to its rows 0,1; parity 1 the other way round: same order of
+        // addition for both pixels of a row pair ((rows 0,1) + (rows 2,3))
+        const float ya = fmaxf((ph == 0 ? keep[e][0] + got.x : got.x + keep[e][0]) + bv, 0.0f);
+        const float yb = fmaxf((ph == 0 ? keep[e][1] + got.y : got.y + keep[e][1]) + bv, 0.0f);
+        const unsigned o0 = 4u * (unsigned)(px * Cout) + nb4;
+        const bool rowok = px >= 0 && (ph == 0 || (fl & 1));
+        const unsigned orow = o0 + (ph ? 4u * (unsigned)(W * Cout) : 0u);
+        wf_store1(rsO, rowok ? orow : OOB, ya);
+        wf_store1(rsO, rowok && (fl & 2) ? orow + 4u * (unsigned)Cout : OOB, yb);
+    }
+    WF_STAMP(4)
+    WF_STAMP(5)
+}
+
+}  // namespace apr

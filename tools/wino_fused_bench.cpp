@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../apr_amd/csrc/wino_fused.hip.h"
+#include "../apr_amd/csrc/wino_fused8.hip.h"
 
 #define CK(x) do { hipError_t r_ = (x); if (r_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(r_)); return 1; } } while (0)
 
@@ -68,7 +68,12 @@ int main(int argc, char **argv)
     }
     const int tiles_n = Cout / apr::WF_BN;
     const long long tiles_m = (T + apr::WF_TT - 1) / apr::WF_TT;
+    const bool k8 = getenv("WF8") != nullptr;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(apr::wino_fused8_f2), hipFuncAttributeMaxDynamicSharedMemorySize, apr::WF_LDS_BYTES));
     auto launch = [&]() {
+        if (k8)
+            hipLaunchKernelGGL(apr::wino_fused8_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw));
+        else
         hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw));
     };
     launch();
