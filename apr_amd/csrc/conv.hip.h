@@ -44,40 +44,53 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // conv1: spec [B][H][W] (C=1) -> out [B][H][W][COUT], 3x3 pad 1 stride 1, + bias, ReLU.
-// 8 lanes per pixel, 4 channels per lane: each pixel's 32 channels are one 128-B store.
-// w1t is [9][32] (tap-major), BN already folded.
+// 8 lanes per pixel, 4 channels per lane: each pixel's 32 channels are one 128-B store.  One
+// work item = 4 consecutive pixels of a row (18 loads and one 32-bit division per 4 pixels; the
+// kernel is bound by its 3 MB/window of stores).  w1t is [9][32] (tap-major), BN already folded.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ spec, const float *__restrict__ w1t,
                                                     const float *__restrict__ bias, float *__restrict__ out,
-                                                    int H, int W, long long n_pixels)
+                                                    int H, int W, unsigned n_rows, unsigned xchunks)
 {
     const int cq = threadIdx.x & 7;
     float4 w[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) w[t] = *reinterpret_cast<const float4 *>(w1t + t * 32 + cq * 4);
     const float4 b = *reinterpret_cast<const float4 *>(bias + cq * 4);
-    const long long stride = (long long)gridDim.x * 32;
-    for (long long p = (long long)blockIdx.x * 32 + (threadIdx.x >> 3); p < n_pixels; p += stride) {
-        const int x = (int)(p % W);
-        const long long t = p / W;
-        const int y = (int)(t % H);
-        const float *base = spec + (t - y) * W;   // start of this window's plane
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const unsigned n_items = n_rows * xchunks;
+    for (unsigned i = blockIdx.x * 32 + (threadIdx.x >> 3); i < n_items; i += gridDim.x * 32) {
+        const unsigned r = i / xchunks;            // row = window * H + y
+        const int x0 = (int)(i - r * xchunks) * 4;
+        const int y = (int)(r % (unsigned)H);
+        const float *row = spec + (size_t)r * W;
+        float v[3][6];
 #pragma unroll
         for (int kh = 0; kh < 3; kh++) {
             const int iy = y + kh - 1;
+            const bool rok = iy >= 0 && iy < H;
 #pragma unroll
-            for (int kw = 0; kw < 3; kw++) {
-                const int ix = x + kw - 1;
-                const float v = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? base[(long long)iy * W + ix] : 0.0f;
-                const float4 ww = w[kh * 3 + kw];
-                acc.x = fmaf(ww.x, v, acc.x); acc.y = fmaf(ww.y, v, acc.y);
-                acc.z = fmaf(ww.z, v, acc.z); acc.w = fmaf(ww.w, v, acc.w);
+            for (int j = 0; j < 6; j++) {
+                const int ix = x0 + j - 1;
+                v[kh][j] = (rok && ix >= 0 && ix < W) ? row[(kh - 1) * W + ix] : 0.0f;
             }
         }
-        acc.x = fmaxf(acc.x + b.x, 0.f); acc.y = fmaxf(acc.y + b.y, 0.f);
-        acc.z = fmaxf(acc.z + b.z, 0.f); acc.w = fmaxf(acc.w + b.w, 0.f);
-        *reinterpret_cast<float4 *>(out + p * 32 + cq * 4) = acc;
+#pragma unroll
+        for (int px = 0; px < 4; px++) {
+            if (x0 + px >= W) break;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const float u = v[kh][px + kw];
+                    const float4 ww = w[kh * 3 + kw];
+                    acc.x = fmaf(ww.x, u, acc.x); acc.y = fmaf(ww.y, u, acc.y);
+                    acc.z = fmaf(ww.z, u, acc.z); acc.w = fmaf(ww.w, u, acc.w);
+                }
+            acc.x = fmaxf(acc.x + b.x, 0.f); acc.y = fmaxf(acc.y + b.y, 0.f);
+            acc.z = fmaxf(acc.z + b.z, 0.f); acc.w = fmaxf(acc.w + b.w, 0.f);
+            *reinterpret_cast<float4 *>(out + ((size_t)r * W + x0 + px) * 32 + cq * 4) = acc;
+        }
     }
 }
 

@@ -513,9 +513,10 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
         }
         ProfScope ps(e, L.slot, flops, bytes);
         if (l == 0) {
-            const long long blocks = std::min<long long>((M + 31) / 32, 256 * 32);
+            const unsigned xchunks = (unsigned)(L.win + 3) / 4, n_rows = (unsigned)(M / L.win);   // M = windows * H * W < 2^31 (max_batch cap)
+            const long long blocks = std::min<long long>(((long long)n_rows * xchunks + 31) / 32, 256 * 32);
             hipLaunchKernelGGL(conv1_kernel, dim3((unsigned)blocks), dim3(256), 0, e->stream, in, L.d_w, L.d_b, out, L.hin,
-                               L.win, M);
+                               L.win, n_rows, xchunks);
         } else if (L.bn_tile == 128) {
             if (L.bm_tile == 64) {
                 if (L.stride == 1) launch_igemm<64, 128, 1>(e, L, in, out, M);
