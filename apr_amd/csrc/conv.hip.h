@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(const float *__restrict__ sp
                 }
             acc.x = fmaxf(acc.x + b.x, 0.f); acc.y = fmaxf(acc.y + b.y, 0.f);
             acc.z = fmaxf(acc.z + b.z, 0.f); acc.w = fmaxf(acc.w + b.w, 0.f);
-            *reinterpret_cast<float4 *>(out + ((size_t)r * W + x0 + px) * 32 + cq * 4) = acc;
+            __builtin_nontemporal_store(f32x4{acc.x, acc.y, acc.z, acc.w}, reinterpret_cast<f32x4 *>(out + ((size_t)r * W + x0 + px) * 32 + cq * 4));
         }
     }
 }
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const float v = acc[i][j][e] + bv;
-                    o[(long long)((e & 3) + 8 * (e >> 2)) * Cout] = MODE == 0 ? fmaxf(v, 0.0f) : v;
+                    __builtin_nontemporal_store(MODE == 0 ? fmaxf(v, 0.0f) : v, o + (long long)((e & 3) + 8 * (e >> 2)) * Cout);
                 }
             } else {
 #pragma unroll

@@ -51,9 +51,12 @@ __device__ __forceinline__ f32x2 wf_sub2(f32x2 a, f32x2 b)
 #endif
 }
 
+#ifndef APR_WF_STORE_AUX
+#define APR_WF_STORE_AUX 0   // 2 = nt (streaming) measured neutral here
+#endif
 __device__ __forceinline__ void wf_store1(__amdgpu_buffer_rsrc_t rs, unsigned voff, float v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, 0, APR_WF_STORE_AUX);
 }
 
 constexpr int WF_TT = 64;                       // tiles per block
