@@ -235,12 +235,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const int kt1 = MODE == 2 ? (int)(((long long)KT * (blockIdx.y + 1)) / gridDim.y) : KT;
 
     f32x4 ra[AROWS], rb[BPASS];
+    // K order for Cin >= 128: (tap row dy, channel chunk, tap column dx).  The three dx taps of one 64-B
+    // channel chunk touch the same input lines shifted by a pixel; run back to back they hit in cache
+    // instead of coming round again Cin/16 K steps later (measured HBM fetch of the stride-2 layers 4..8:
+    // -17 %).  Narrow layers (Cin = 32: one pixel = one 128-B line = two chunks) keep tap-major order,
+    // which reads both halves of a line in consecutive K steps (the other order fetched 30 % more).
+    const bool dx_inner = MODE != 1 && cchunks >= 8;
+#define APR_KT_SPLIT(KT_)                                                                                \
+        int tap_, c0_;                                                                                   \
+        if (dx_inner) {                                                                                  \
+            const int dy_ = (KT_) / (3 * cchunks);                                                       \
+            const int rem_ = (KT_) - dy_ * 3 * cchunks;                                                  \
+            const int cc_ = rem_ / 3;                                                                    \
+            tap_ = 3 * dy_ + (rem_ - 3 * cc_);                                                           \
+            c0_ = cc_ * BK;                                                                              \
+        } else {                                                                                         \
+            tap_ = MODE != 1 ? (KT_) / cchunks : 0;                                                      \
+            c0_ = ((KT_) - tap_ * cchunks) * BK;                                                         \
+        }
 #define APR_LOAD_TILES(KT_)                                                                              \
     {                                                                                                    \
-        const int tap_ = (KT_) / cchunks;                                                                \
-        const int c0_ = ((KT_) - tap_ * cchunks) * BK;                                                   \
+        APR_KT_SPLIT(KT_)                                                                                \
         const int soffA_ = MODE != 1 ? 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_) : 4 * c0_;        \
-        const int soffB_ = 4 * (KT_) * BK * Cout;                                                        \
+        const int soffB_ = 4 * (tap_ * Cin + c0_) * Cout;                                                \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
             const unsigned vo_ = ((rowmask[i] >> tap_) & 1u) ? rowoff[i] : OOB;                          \
@@ -255,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     // 1 KiB = 64 lanes x 16 B contiguously, which is exactly (64/BCH) whole k-rows of Bs.
 #define APR_DMA_B(KT_, BUF_)                                                                             \
     {                                                                                                    \
-        const int soffB_ = 4 * (KT_) * BK * Cout;                                                        \
+        APR_KT_SPLIT(KT_)                                                                                \
+        const int soffB_ = 4 * (tap_ * Cin + c0_) * Cout;                                                \
         const unsigned lds_ = bs_lds + 4u * (unsigned)((BUF_) * BK * BN);                                \
         _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                                \
             lds_dma_b128(rsBv, boff[i], soffB_, lds_ + 4u * (unsigned)(BROWS * i * BN));                 \
@@ -364,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 }
 
 #undef APR_LOAD_TILES
+#undef APR_KT_SPLIT
 #undef APR_STORE_A
 #undef APR_STORE_B
 #undef APR_DMA_B
