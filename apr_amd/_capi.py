@@ -21,6 +21,7 @@ SYMBOLS = (
     "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable",
     "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
+    "apr_resample_taps", "apr_upsample", "apr_upsample_device",
 )
 
 
@@ -87,6 +88,12 @@ def lib():
     L.apr_wav_data_offset.restype = C.c_size_t
     L.apr_bucket_hits.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]
     L.apr_bucket_hits.restype = C.c_int
+    L.apr_resample_taps.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, vp]
+    L.apr_resample_taps.restype = C.c_int
+    L.apr_upsample.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp]
+    L.apr_upsample.restype = C.c_int
+    L.apr_upsample_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp]
+    L.apr_upsample_device.restype = C.c_int
     L.apr_sync.argtypes = [vp]
     L.apr_sync.restype = C.c_int
     L.apr_engine_stream.argtypes = [vp]

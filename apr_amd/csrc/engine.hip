@@ -18,6 +18,7 @@
 #include "frontend.hip.h"
 #include "model_parse.h"
 #include "wino.hip.h"
+#include "resample.hip.h"
 #include "wino_fused.hip.h"
 #include "wino_fused8.hip.h"
 
@@ -55,6 +56,9 @@ struct apr_engine {
     std::string err;
     int n_classes = 0;
     int max_batch = 1024;
+    int16_t *d_rs_in = nullptr, *d_rs_out = nullptr;   // apr_upsample staging (host-pointer form)
+    double *d_rs_taps = nullptr;
+    size_t rs_cap = 0, rs_out_cap = 0;
     int features = 0, pool_pixels = 0;
 
     // front end
@@ -859,6 +863,68 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
     return APR_OK;
 }
 
+
+// ---- integer-factor upsampler (resample.hip.h) ----
+static int upsample_check(apr_engine *e, size_t n_in, int up, const double *taps, int tpp, const void *in, const void *out)
+{
+    if (up < 1 || tpp < 2 || tpp % 2 || up * tpp > apr::kResampleMaxTaps || !taps || (n_in && (!in || !out)) || n_in > ((size_t)1 << 40)) {
+        e->err = "apr_upsample: bad argument (need up >= 1, even taps_per_phase, up * taps_per_phase <= 1024)";
+        return APR_ERR_INVALID;
+    }
+    return APR_OK;
+}
+
+static int upsample_taps_to_device(apr_engine *e, const double *taps, int n)
+{
+    int rc;
+    if (!e->d_rs_taps && (rc = dev_alloc(e, &e->d_rs_taps, (size_t)apr::kResampleMaxTaps))) return rc;
+    HIPCHK(e, hipMemcpyAsync(e->d_rs_taps, taps, (size_t)n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    return APR_OK;
+}
+
+int apr_upsample_device(apr_engine *e, const int16_t *d_in, size_t n_in, int up, const double *taps, int taps_per_phase, int16_t *d_out)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if ((rc = upsample_check(e, n_in, up, taps, taps_per_phase, d_in, d_out))) return rc;
+    if (!n_in) return APR_OK;
+    if ((rc = upsample_taps_to_device(e, taps, up * taps_per_phase))) return rc;
+    const long long n_out = (long long)n_in * up;
+    const unsigned blocks = (unsigned)std::min<long long>((n_out + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(apr::upsample_fir_kernel, dim3(blocks), dim3(256), 0, e->stream, d_in, 0LL, (long long)n_in, up, taps_per_phase,
+                       e->d_rs_taps, d_out, 0LL, n_out);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // `taps` is the caller's host memory: the copy must be done on return
+    return APR_OK;
+}
+
+int apr_upsample(apr_engine *e, const int16_t *in, size_t n_in, int up, const double *taps, int taps_per_phase, int16_t *out)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if ((rc = upsample_check(e, n_in, up, taps, taps_per_phase, in, out))) return rc;
+    if (!n_in) return APR_OK;
+    if ((rc = upsample_taps_to_device(e, taps, up * taps_per_phase))) return rc;
+    const size_t chunk = (size_t)1 << 22, halo = (size_t)taps_per_phase;   // input samples per pass
+    if (!e->d_rs_in || e->rs_cap < chunk + 2 * halo || e->rs_out_cap < chunk * (size_t)up) {
+        if ((rc = dev_alloc(e, &e->d_rs_in, chunk + 2 * halo)) || (rc = dev_alloc(e, &e->d_rs_out, chunk * (size_t)up))) return rc;
+        e->rs_cap = chunk + 2 * halo;
+        e->rs_out_cap = chunk * (size_t)up;
+    }
+    for (size_t m0 = 0; m0 < n_in; m0 += chunk) {
+        const size_t m1 = std::min(n_in, m0 + chunk);
+        const size_t lo = m0 > halo ? m0 - halo : 0, hi = std::min(n_in, m1 + halo);
+        HIPCHK(e, hipMemcpyAsync(e->d_rs_in, in + lo, (hi - lo) * sizeof(int16_t), hipMemcpyHostToDevice, e->stream));
+        const long long n_count = (long long)(m1 - m0) * up;
+        const unsigned blocks = (unsigned)std::min<long long>((n_count + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(apr::upsample_fir_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_rs_in, (long long)lo, (long long)n_in, up,
+                           taps_per_phase, e->d_rs_taps, e->d_rs_out, (long long)m0 * up, n_count);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipMemcpyAsync(out + m0 * (size_t)up, e->d_rs_out, (size_t)n_count * sizeof(int16_t), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    }
+    return APR_OK;
+}
 
 size_t apr_windows_in(size_t nbytes, size_t stride_bytes)
 {

@@ -196,6 +196,23 @@ class Engine:
                                             label.ctypes.data, match.ctypes.data, first))
         return dict(probs=probs, label=label, match=match, first_window=np.asarray(list(first), np.int64))
 
+    def upsample(self, pcm, up: int = 3, taps=None) -> np.ndarray:
+        """apr_upsample: s16 PCM at rate r (host array) -> s16 PCM at rate ``up`` x r, on the GPU.  16 kHz sources
+        become the 48 kHz this path scores; the reference delegates this to ffmpeg (src/ffmpeg/ffmpeg.go:76)."""
+        from .sweep import resample_taps
+        x = np.ascontiguousarray(pcm, np.int16).reshape(-1)
+        t = np.ascontiguousarray(resample_taps(up) if taps is None else taps, np.float64)
+        if t.ndim != 2 or t.shape[0] != up:
+            raise ValueError("taps must be [up, taps_per_phase]")
+        out = np.empty(x.size * up, np.int16)
+        self._chk(self._lib.apr_upsample(self._h, x.ctypes.data, x.size, up, t.ctypes.data, t.shape[1], out.ctypes.data))
+        return out
+
+    def upsample_device(self, d_in, n_in: int, d_out, up: int = 3, taps=None) -> None:
+        from .sweep import resample_taps
+        t = np.ascontiguousarray(resample_taps(up) if taps is None else taps, np.float64)
+        self._chk(self._lib.apr_upsample_device(self._h, _addr(d_in), n_in, up, t.ctypes.data, t.shape[1], _addr(d_out)))
+
     # ---- device-resident entry points (torch tensors on this engine's GPU) ----
     def score_device(self, d_pcm, total_bytes: int, n_windows: int, stride: int, trust: float, empty_class: int,
                      d_probs=None, d_label=None, d_match=None, d_logits=None) -> None:

@@ -169,6 +169,17 @@ def bucket_hits(label, match, n_classes: int, windows_per_bucket: int = 60) -> n
     return hits
 
 
+def resample_taps(up: int = 3, taps_per_phase: int = 32, cutoff: float = 0.97, beta: float = 9.0) -> np.ndarray:
+    """apr_resample_taps: [up, taps_per_phase] f64 polyphase low-pass (Kaiser-windowed sinc, each phase sums to 1).
+    The reference leaves this step to ffmpeg's ``-ar 48000`` (src/ffmpeg/ffmpeg.go:76,113-114)."""
+    from . import _capi
+    taps = np.empty((up, taps_per_phase), np.float64)
+    rc = _capi.lib().apr_resample_taps(up, taps_per_phase, cutoff, beta, taps.ctypes.data)
+    if rc != 0:
+        raise _capi.AprError(rc, "apr_resample_taps: bad argument")
+    return taps
+
+
 # ----------------------------------------------------------------------------------------------
 # multi-model fan-out: one spectrogram, every configured model
 # (src/daemon/daemon.go:93-99,132-136 and ai/inspect.py:133-159)

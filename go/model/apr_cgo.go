@@ -251,6 +251,29 @@ func WavDataOffset(head []byte) int {
 	return int(C.apr_wav_data_offset((*C.uint8_t)(unsafe.Pointer(&head[0])), C.size_t(len(head)), nil, nil, nil))
 }
 
+// Upsample3 turns 16 kHz s16 PCM into the 48 kHz the scoring path expects, on the GPU (apr_upsample with the
+// library's default 3 x 32-tap Kaiser low-pass).  The reference asks ffmpeg for `-ar 48000` instead
+// (src/ffmpeg/ffmpeg.go:76,113-114); this is for sources that reach the daemon without ffmpeg.
+func Upsample3(pcm16k []int16) []int16 {
+	if len(pcm16k) == 0 {
+		return nil
+	}
+	var taps [3 * 32]C.double
+	if rc := C.apr_resample_taps(3, 32, 0.97, 9.0, &taps[0]); rc != 0 {
+		log.Die("apr_resample_taps failed: %d", int(rc))
+	}
+	out := make([]int16, 3*len(pcm16k))
+	e := frontend()
+	e.mu.Lock()
+	rc := C.apr_upsample(e.h, (*C.int16_t)(unsafe.Pointer(&pcm16k[0])), C.size_t(len(pcm16k)), 3, &taps[0], 32,
+		(*C.int16_t)(unsafe.Pointer(&out[0])))
+	e.mu.Unlock()
+	if rc < 0 {
+		log.Die("Upsample failed: %s", lastErr(e.h))
+	}
+	return out
+}
+
 // BucketHits folds per-window matches into one hit per class per minute (docs/usage/review.md:48-53).
 func BucketHits(label []int32, match []bool, nClasses int) [][]bool {
 	n := len(label)

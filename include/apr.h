@@ -203,6 +203,23 @@ int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const
 size_t apr_wav_data_offset(const uint8_t *buf, size_t n, uint32_t *sample_rate, uint16_t *channels, uint16_t *bits_per_sample);
 
 /*
+ * Integer-factor upsampling of s16 PCM on the GPU (16 kHz sources -> the 48 kHz this path scores,
+ * up = 3).  In the reference this is ffmpeg's `-ar 48000 -ac 1` inside both decode commands
+ * (src/ffmpeg/ffmpeg.go:76,113-114; ai/inspect.py:99-100); libswresample cannot be matched bit for
+ * bit, so this step is outside the parity claim and uses the library's own filter:
+ *   out[up m + p] = round_half_even_sat16( sum_{k < tpp} taps[p][k] * in[m + tpp/2 - k] ),  in[] = 0 outside
+ * in f64 with one rounded multiply and add per tap (oracle/resample.py reproduces the bits).
+ * apr_resample_taps fills taps[up][taps_per_phase] (host memory) with a Kaiser(beta)-windowed sinc whose
+ * cutoff is `cutoff` x the input Nyquist, each phase scaled to sum 1; taps_per_phase even,
+ * up * taps_per_phase <= 1024.  Suggested: up 3, taps_per_phase 32, cutoff 0.97, beta 9.0.
+ * apr_upsample: host pointers, out holds n_in * up samples; apr_upsample_device: device pointers
+ * (taps stay in host memory).  Both return after the work is done.
+ */
+int apr_resample_taps(int up, int taps_per_phase, double cutoff, double beta, double *taps);
+int apr_upsample(apr_engine *e, const int16_t *in, size_t n_in, int up, const double *taps, int taps_per_phase, int16_t *out);
+int apr_upsample_device(apr_engine *e, const int16_t *d_in, size_t n_in, int up, const double *taps, int taps_per_phase, int16_t *d_out);
+
+/*
  * Report bucketing: hits[b][c] = 1 iff some window k in [b*wpb, (b+1)*wpb) has match[k] and
  * label[k] == c -- "1 clap or 999 claps within 1 minute is logged as one hit"
  * (docs/usage/review.md:48-53; the reference's code does not implement it).  wpb = 60 at the 1-s hop.

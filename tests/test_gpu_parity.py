@@ -353,3 +353,40 @@ def test_full_size_sweep_properties(he_weights):
     lines = sweep.format_matches("m", LABELS, {f: f"rec{f}.mkv" for f in range(n_files)}, plan, label, match)
     assert len(lines) == int((match.astype(bool) & plan.valid).sum())
     eng.close()
+
+
+def test_upsample_bit_exact_with_oracle_definition(fe):
+    # 16 kHz -> 48 kHz ahead of the path (the reference leaves it to ffmpeg: src/ffmpeg/ffmpeg.go:76,113-114); no reference
+    # vector exists, so the oracle here is the restatement of include/apr.h's formula -- parity with ffmpeg is NOT claimed
+    from oracle import resample as R
+    rng = np.random.default_rng(5)
+    taps = sweep.resample_taps()
+    for n in (0, 1, 5, 31, 1000, 48000):
+        x = rng.integers(-32768, 32768, n).astype(np.int16)          # full-scale noise: exercises saturation
+        got = fe.upsample(x)
+        assert got.dtype == np.int16 and got.size == 3 * n
+        assert np.array_equal(got, R.upsample(x, 3, taps))
+    # other factor / filter; a run that crosses the 4 Mi-sample staging chunk
+    t2 = sweep.resample_taps(2, 16, 0.9, 6.0)
+    x = rng.integers(-3000, 3000, 7777).astype(np.int16)
+    assert np.array_equal(fe.upsample(x, 2, t2), R.upsample(x, 2, t2))
+    x = (rng.standard_normal((1 << 22) + 777) * 2000).astype(np.int16)
+    got = fe.upsample(x)
+    want = R.upsample(x, 3, taps)
+    assert np.array_equal(got, want)
+    # device-pointer form
+    import torch
+    dx = torch.from_numpy(x[:100000].copy()).cuda()
+    dy = torch.empty(300000, dtype=torch.int16, device="cuda")
+    fe.upsample_device(dx, 100000, dy)
+    assert np.array_equal(dy.cpu().numpy(), R.upsample(x[:100000], 3, taps))
+    # properties: DC passes at gain 1; an in-band tone keeps its amplitude and frequency
+    dc = fe.upsample(np.full(4000, 1234, np.int16))
+    assert np.all(dc[200:-200] == 1234)
+    tt = np.arange(16000)
+    tone = np.round(8000 * np.sin(2 * np.pi * 1000 * tt / 16000)).astype(np.int16)
+    up = fe.upsample(tone).astype(np.float64)
+    ref = 8000 * np.sin(2 * np.pi * 1000 * np.arange(48000) / 48000)
+    assert np.abs(up[300:-300] - ref[300:-300]).max() <= 8.0           # 1 kHz: passband ripple + input/output rounding
+    with pytest.raises(AprError):
+        fe.upsample(x[:10], 3, np.zeros((3, 31)))

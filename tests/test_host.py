@@ -179,3 +179,19 @@ def test_c_windows_in_matches_inspect_py():
         assert L.apr_windows_in(n, 96000) == sweep.windows_in(n) == len(range(0, max(n - 96000, 0), 96000))
     assert L.apr_windows_in(10 * 192000, 192000) == sweep.windows_in(10 * 192000, 192000) == 9
     assert L.apr_windows_in(1000, 0) == 0
+
+
+def test_resample_taps_match_oracle_definition():
+    # no reference vector exists for this step (ffmpeg does it upstream): the library is pinned to its own published definition
+    from oracle import resample as R
+    for up, tpp, cutoff, beta in ((3, 32, 0.97, 9.0), (2, 16, 0.9, 6.0), (1, 2, 1.0, 0.0), (4, 256, 0.5, 12.0)):
+        t = sweep.resample_taps(up, tpp, cutoff, beta)
+        assert t.shape == (up, tpp)
+        np.testing.assert_allclose(t, R.resample_taps(up, tpp, cutoff, beta), rtol=0, atol=1e-13)
+        np.testing.assert_allclose(t.sum(axis=1), 1.0, atol=1e-14)          # DC gain 1 in every phase
+    t = sweep.resample_taps()
+    assert np.argmax(t[0]) == 16 and t[0, 16] > 0.9                          # phase 0 sits on the input sample
+    np.testing.assert_allclose(t[1], t[2][::-1], atol=1e-15)                 # phases 1 and 2 mirror each other
+    for bad in ((0, 32, 0.97, 9.0), (3, 31, 0.97, 9.0), (3, 0, 0.97, 9.0), (3, 512, 0.97, 9.0), (3, 32, 0.0, 9.0), (3, 32, 1.5, 9.0), (3, 32, 0.97, -1.0)):
+        with pytest.raises(_capi.AprError):
+            sweep.resample_taps(*bad)
