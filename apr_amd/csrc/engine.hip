@@ -19,6 +19,7 @@
 #include "model_parse.h"
 #include "wino.hip.h"
 #include "resample.hip.h"
+#include "conv12_fused.hip.h"
 #include "wino_fused.hip.h"
 #include "wino_fused8.hip.h"
 
@@ -56,6 +57,8 @@ struct apr_engine {
     std::string err;
     int n_classes = 0;
     int max_batch = 1024;
+    bool fuse12 = false;   // layers 1 + 2 run as conv12_fused_kernel (conv1's output never goes to HBM)
+    int n_cus = 256;       // compute units of the device (persistent-kernel grids)
     int16_t *d_rs_in = nullptr, *d_rs_out = nullptr;   // apr_upsample staging (host-pointer form)
     double *d_rs_taps = nullptr;
     size_t rs_cap = 0, rs_out_cap = 0;
@@ -344,6 +347,16 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
         h = L.hout; w = L.wout;
         e->layers.push_back(L);
     }
+    // layers 1 + 2 in one kernel when they are the reference's (1 -> 32 stride 1, 32 -> 64 stride 2); APR_FUSE12=0: two kernels
+    // (latency engines keep the two kernels: 48 tiles of one clip leave most CUs idle and measured 20 us slower)
+    if (e->layers.size() >= 2 && e->max_batch > 4 && !(getenv("APR_FUSE12") && atoi(getenv("APR_FUSE12")) == 0)) {
+        const Layer &a = e->layers[0];
+        Layer &b = e->layers[1];
+        if (a.cin == 1 && a.cout == 32 && a.stride == 1 && b.cin == 32 && b.cout == 64 && b.stride == 2 && !b.wino) {
+            e->fuse12 = true;
+            b.ksplit = 1;
+        }
+    }
     e->n_classes = pm.n_classes;
     e->features = pm.features;
     e->pool_pixels = h * w;
@@ -461,6 +474,18 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
         const long long M = (long long)batch * L.hout * L.wout;
         const double flops = 2.0 * (double)M * L.cout * 9.0 * L.cin;
         const double bytes = 4.0 * ((double)batch * L.hin * L.win * L.cin + (double)M * L.cout + 9.0 * L.cin * L.cout);
+        if (e->fuse12 && l == 0) continue;   // computed inside layer 2's kernel
+        if (e->fuse12 && l == 1) {
+            const int tiles_x = (L.wout + C12_TW - 1) / C12_TW, tiles_y = (L.hout + C12_TH - 1) / C12_TH;
+            const Layer &L0 = e->layers[0];
+            ProfScope ps(e, L.slot, flops + 2.0 * 9.0 * 32.0 * (double)batch * L.hin * L.win,
+                         4.0 * ((double)batch * L.hin * L.win + (double)M * L.cout + 9.0 * L.cin * L.cout));
+            const unsigned n_tiles = (unsigned)batch * (unsigned)(tiles_x * tiles_y);   // <= 16384 * 48
+            hipLaunchKernelGGL(conv12_fused_kernel, dim3(std::min(n_tiles, 2u * (unsigned)e->n_cus)), dim3(256), C12_LDS_BYTES, e->stream, d_spec,
+                               L0.d_w, L0.d_b, L.d_w, L.d_b, out, L.hin, L.win, L.hout, L.wout, tiles_x, tiles_y, n_tiles);
+            in = out;
+            continue;
+        }
         if (L.wino == 3) {
             const long long T = (long long)batch * L.th * L.tw;   // < 2^31: max_batch is capped at create
             const int tiles_n = L.cout / WF_BN;
@@ -632,13 +657,20 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         e->err = "could not reserve LDS for wino_fused_f2";
         rc = APR_ERR_DEVICE;
     }
+    if (!rc && (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || e->n_cus < 1)) e->n_cus = 256;
+    if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(conv12_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C12_LDS_BYTES) != hipSuccess) {
+        e->err = "could not reserve LDS for conv12_fused_kernel";
+        rc = APR_ERR_DEVICE;
+    }
     if (!rc) rc = build_frontend(e);
     if (!rc && has_model) rc = build_cnn(e, pm);
     if (!rc && has_model) {
         for (size_t l = 0; l < e->layers.size(); l++) {
             Layer &L = e->layers[l];
             char nm[48];
-            if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
+            if (e->fuse12 && l == 0) continue;   // no kernel of its own
+            if (e->fuse12 && l == 1) snprintf(nm, sizeof nm, "conv12_fused_kernel");
+            else if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
             else if (L.wino) {
                 L.slot_in = e->n_slots;
                 add_slot(e, "wino_input_f2", (int)l + 1);

@@ -257,6 +257,8 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
     unfused = run({"APR_WINO_FUSED": "0", "APR_WINO_MIN_CIN": "64"})    # every stride-1 igemm layer, three-kernel form
     fused = run({"APR_WINO_FUSED_MAX_CIN": "512"})                      # every stride-1 igemm layer, one-kernel form
     fused1 = run({"APR_WINO_FUSED_MAX_CIN": "512", "APR_SPLITK": "0"}, batch=1)   # ragged tile blocks (6 windows in chunks of 1)
+    two12 = run({"APR_FUSE12": "0"})                                    # layers 1 and 2 as two kernels: same fma chains, same bits
+    assert np.array_equal(default, two12)
     fused4 = run({"APR_WINO_FUSED_MAX_CIN": "512", "APR_WINO_FUSED_WAVES": "4"})  # the four-wave kernel: output transform summed in another order
     assert np.abs(fused - fused4).max() <= 2e-5         # logits, after 12 layers of last-bit differences
     for got in (direct, default, unfused, fused, fused1):
