@@ -36,7 +36,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--files", type=int, default=60, help="recordings per GPU")
     ap.add_argument("--seconds", type=int, default=600, help="seconds per recording")
-    ap.add_argument("--max-batch", type=int, default=1024)
+    ap.add_argument("--max-batch", type=int, default=2048, help="windows per GPU pass")
     ap.add_argument("--cpu-windows", type=int, default=96, help="windows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -156,12 +156,13 @@ def main() -> int:
         dom_name, dom = max(((k, v) for k, v in fam.items() if "igemm" in k or "wino_fused" in k), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         # HBM bytes per launch from the committed PMC passes (tools/pmc_traffic.py; FETCH_SIZE and
-        # WRITE_SIZE cannot be collected inside this process).  Valid for 1024-window launches only.
+        # WRITE_SIZE cannot be collected inside this process).  Valid for launches of the profiled size only.
         traffic = None
         try:
-            if args.max_batch == 1024:
-                with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
-                    traffic = json.load(fh)["kernels"][dom_name]["hbm_bytes_per_launch"]
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if args.max_batch == pmc["windows_per_launch"]:
+                traffic = pmc["kernels"][dom_name]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             traffic = None
         out["roofline"] = {"kernel": dom_name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,

@@ -67,8 +67,8 @@ func frontend() *engine {
 
 func engineFor(m OnnxModel) *engine { return cachedEngine(m, 1, engines) }
 
-// batchEngineFor: the engine of ScoreBatch / SweepFiles (1024 windows per GPU pass).
-func batchEngineFor(m OnnxModel) *engine { return cachedEngine(m, 1024, batchEngines) }
+// batchEngineFor: the engine of ScoreBatch / SweepFiles (2048 windows per GPU pass).
+func batchEngineFor(m OnnxModel) *engine { return cachedEngine(m, 2048, batchEngines) }
 
 // Infer scores one clip per call (daemon.go:132-136), so its engine is created with max_batch 1:
 // a few MB of activations instead of 8 GB, and the library runs the late, tiny-grid layers split

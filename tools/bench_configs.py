@@ -57,7 +57,7 @@ def main():
     eng.close()
 
     # ---------------- host-pointer sweep (PCIe inclusive) ----------------
-    eng = model.Engine(W.pack_blob(W.random_init(C, 0, "he"), C), 0, 1024)
+    eng = model.Engine(W.pack_blob(W.random_init(C, 0, "he"), C), 0, 2048)
     files = [model.synth_pcm(0, f, args.sweep_seconds) for f in range(args.sweep_files)]
     eng.sweep_files(files[:2], trust=0.5, empty_class=2)           # warm-up: allocates the staging buffers
     t0 = time.perf_counter()

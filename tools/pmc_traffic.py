@@ -3,7 +3,7 @@
 into per-kernel HBM traffic per launch.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- \
-        python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 513
+        python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 1025
     rocprofv3 --pmc WRITE_SIZE ... -d gpurun_out/pmc_write ...
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
 
@@ -34,6 +34,7 @@ def short(name):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    wpl = int(sys.argv[4]) if len(sys.argv) > 4 else 2048   # windows of the profiled pass (bench.py --max-batch)
     f, w = load(fetch), load(write)
     per = collections.OrderedDict()
     fl = list(f.items())
@@ -51,7 +52,7 @@ def main():
         a["write_bytes"] += wv * 1024.0
     for a in per.values():
         a["hbm_bytes_per_launch"] = (a["fetch_bytes"] + a["write_bytes"]) / a["launches"]
-    json.dump({"windows_per_launch": 1024, "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane streams), KiB units",
+    json.dump({"windows_per_launch": wpl, "correction": "FETCH_SIZE x2 (gfx950, 16 B/lane streams), KiB units",
                "kernels": per}, open(out, "w"), indent=1)
     for k, a in per.items():
         print(f"{k:40s} launches {a['launches']:2d}  HBM/launch {a['hbm_bytes_per_launch'] / 1e6:9.1f} MB")
