@@ -270,7 +270,9 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     const char *fenv = getenv("APR_WINO_FUSED");
     const bool fused_on = wino_on && !(fenv && fenv[0] == '0');
     const char *fcenv = getenv("APR_WINO_FUSED_MAX_CIN");
-    const int fused_max_cin = fcenv ? atoi(fcenv) : 256;
+    // Cin = 512 (layers 9, 11): the one-kernel form wins once a pass holds enough tiles to fill the chip (measured at
+    // 2048 windows: 58.0 vs 67.6 ms and 29.0 vs 31.9 ms a step); small engines keep transform kernels + batched GEMM there
+    const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
         Layer L;

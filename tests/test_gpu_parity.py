@@ -253,7 +253,7 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
         return out
 
     direct = run({"APR_WINOGRAD": "0"})
-    default = run({})
+    default = run({})                                                   # batch 8: fused up to Cin 256, three kernels above
     unfused = run({"APR_WINO_FUSED": "0", "APR_WINO_MIN_CIN": "64"})    # every stride-1 igemm layer, three-kernel form
     fused = run({"APR_WINO_FUSED_MAX_CIN": "512"})                      # every stride-1 igemm layer, one-kernel form
     fused1 = run({"APR_WINO_FUSED_MAX_CIN": "512", "APR_SPLITK": "0"}, batch=1)   # ragged tile blocks (6 windows in chunks of 1)
