@@ -497,8 +497,8 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
                 hipLaunchKernelGGL(wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
                                    out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
             else
-                hipLaunchKernelGGL(wino_fused8_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
-                                   out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
+                hipLaunchKernelGGL(wino_fused8_f2, dim3(wf8_grid((int)(tiles_m * tiles_n), e->n_cus)), dim3(512), WF8_LDS_BYTES, e->stream, in, L.d_u,
+                                   L.d_b, out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw), (int)(tiles_m * tiles_n));
             in = out;
             continue;
         }
@@ -655,7 +655,7 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         rc = APR_ERR_DEVICE;
     }
     if (!rc && (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused8_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF_LDS_BYTES) != hipSuccess)) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(wino_fused8_f2), hipFuncAttributeMaxDynamicSharedMemorySize, WF8_LDS_BYTES) != hipSuccess)) {
         e->err = "could not reserve LDS for wino_fused_f2";
         rc = APR_ERR_DEVICE;
     }

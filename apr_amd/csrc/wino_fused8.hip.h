@@ -8,6 +8,9 @@
 // the waves of one parity issue the patch loads of chunk k+2 while the waves of the other parity
 // transform and store chunk k+1 and DMA its U image (one register set per wave, no wave ever has
 // loads and a DMA in flight together, so every vmcnt wait is exact).
+// Workgroups are persistent (one per CU): before a unit's epilogue the next unit's tile table, patch
+// offsets, first patch loads and first U DMA are issued, so their latency runs under the epilogue's
+// VALU work and LDS exchange instead of in front of the next K loop.
 // Epilogue: the output transform is linear in the positions, so each wave reduces its 8 positions
 // to partial 2x2 outputs, the pair swaps halves through LDS (the idle Vs buffers) and each wave
 // finishes and stores two of the four pixels.
@@ -18,14 +21,24 @@
 
 namespace apr {
 
+constexpr int WF8_LDS_BYTES = 2 * 2 * WF_POS * 4 + 2 * WF_TT * 8;   // Vs[2], Us[2], two tile tables
+
+// grid of the persistent kernel: one workgroup per CU, a multiple of 8 (one share per XCD), no more than the units need
+inline unsigned wf8_grid(int n_units, int n_cus)
+{
+    const int cap = n_cus >= 8 ? (n_cus / 8) * 8 : 8;
+    return (unsigned)(n_units >= cap ? cap : ((n_units + 7) / 8) * 8);
+}
+
 __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ in, const float *__restrict__ up,
                                                       const float *__restrict__ bias, float *__restrict__ out, int H,
-                                                      int W, int Cin, int Cout, int th, int tw, int T, int tiles_n, WfMagic mg)
+                                                      int W, int Cin, int Cout, int th, int tw, int T, int tiles_n, WfMagic mg,
+                                                      int n_units)
 {
     extern __shared__ __attribute__((aligned(16))) float wf_smem[];
     float *Vs = wf_smem;                        // [2][WF_POS]; after the K loop: the pairs' exchange buffers
     float *Us = wf_smem + 2 * WF_POS;           // [2][WF_POS]
-    int *tbl = reinterpret_cast<int *>(wf_smem + 4 * WF_POS);   // [64][2]: output pixel of (b, 2ty, 2tx) or -1; flags
+    int *tbl = reinterpret_cast<int *>(wf_smem + 4 * WF_POS);   // [2][64][2]: output pixel of (b, 2ty, 2tx) or -1; flags (one table per unit in flight)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ph = wave & 1;                    // which 8 of the 16 positions; also the staging parity
@@ -33,51 +46,61 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     const int wm = sub >> 1, wn = sub & 1;
     const int li = lane & 31, half = lane >> 5;
     const int sid = sub * 64 + lane;            // 0..255 among the four waves of one parity
+    const int t_ld = sid >> 2, cp = sid & 3;    // every parity stages whole chunks: 256 threads = 64 tiles x 4 channel pairs
     WF_STAMP(0)
 
-    // XCD-aware block order (see conv3x3_igemm_f32)
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
-    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int bm = wf_div(lid, mg.tiles_n);
-    const int bn = lid - bm * tiles_n;
-    const int g0 = bm * WF_TT;                   // first tile of the block (< T)
-    const int b0 = wf_div(g0, mg.tpw);           // its window
+    // Persistent workgroups, XCD-aware: the units are cut into 8 contiguous runs, one per XCD (neighbouring
+    // units share input rows or weights and so an L2); the gridDim.x / 8 workgroups of an XCD walk its run.
+    const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;       // gridDim.x is a multiple of 8 (host)
+    const int uq = n_units >> 3, ur = n_units & 7;
+    const int x_start = xcd < ur ? xcd * (uq + 1) : ur * (uq + 1) + (xcd - ur) * uq;
+    const int x_count = uq + (xcd < ur ? 1 : 0);
+    int lidl = blockIdx.x >> 3;
+    if (lidl >= x_count) return;                // whole workgroup: nothing to do
 
-    // ---- input patch addressing (every parity stages whole chunks: 256 threads = 64 tiles x 4 channel pairs) ----
     constexpr unsigned OOB = 0x80000000u;
-    const float *abase = in + (((long long)b0 * H - 1) * W - 1) * (long long)Cin;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)abase, 0, 0x40000000, 0x00020000);
-    const int t_ld = sid >> 2, cp = sid & 3;
-    unsigned voff = OOB, vmask = 0;
-    {
-        int tpx = -1, tfl = 0;
-        const int g = g0 + t_ld;
-        if (g < T) {
-            const int rr = wf_div(g, mg.tw);
-            const int tx = g - rr * tw;
-            const int bb = wf_div(rr, mg.th);
-            const int ty = rr - bb * th;
-            const int db = bb - b0;
-            const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-            voff = 4u * (unsigned)(((db * H + y0 + 1) * W + x0 + 1) * Cin + 2 * cp);
-            tpx = (db * H + 2 * ty) * W + 2 * tx;
-            tfl = (2 * ty + 1 < H ? 1 : 0) | (2 * tx + 1 < W ? 2 : 0);
-            const unsigned rowok = (ty > 0 ? 1u : 0u) | 2u | (2 * ty + 1 < H ? 4u : 0u) | (2 * ty + 2 < H ? 8u : 0u);
-            const unsigned colok = (tx > 0 ? 1u : 0u) | 2u | (2 * tx + 1 < W ? 4u : 0u) | (2 * tx + 2 < W ? 8u : 0u);
-#pragma unroll
-            for (int i = 0; i < 4; i++) vmask |= ((rowok >> i) & 1u) ? colok << (4 * i) : 0u;
-        }
-        if (cp == 0 && ph == 0) {
-            tbl[2 * t_ld] = tpx;
-            tbl[2 * t_ld + 1] = tfl;
-        }
+    // unit LID -> its N tile BN_, first window B0_, this lane's patch offset VOFF_ / validity mask VMASK_, and the
+    // tile table TB_ (zero padding = out-of-range buffer offsets)
+#define W8_SETUP(LID_, TB_, BN_, B0_, VOFF_, VMASK_)                                                     \
+    {                                                                                                    \
+        const int bm_ = wf_div((LID_), mg.tiles_n);                                                      \
+        BN_ = (LID_) - bm_ * tiles_n;                                                                    \
+        const int g0_ = bm_ * WF_TT;                                                                     \
+        B0_ = wf_div(g0_, mg.tpw);                                                                       \
+        VOFF_ = OOB; VMASK_ = 0;                                                                         \
+        int tpx_ = -1, tfl_ = 0;                                                                         \
+        const int g_ = g0_ + t_ld;                                                                       \
+        if (g_ < T) {                                                                                    \
+            const int rr_ = wf_div(g_, mg.tw);                                                           \
+            const int tx_ = g_ - rr_ * tw;                                                               \
+            const int bb_ = wf_div(rr_, mg.th);                                                          \
+            const int ty_ = rr_ - bb_ * th;                                                              \
+            const int db_ = bb_ - B0_;                                                                   \
+            const int y0_ = 2 * ty_ - 1, x0_ = 2 * tx_ - 1;                                              \
+            VOFF_ = 4u * (unsigned)(((db_ * H + y0_ + 1) * W + x0_ + 1) * Cin + 2 * cp);                 \
+            tpx_ = (db_ * H + 2 * ty_) * W + 2 * tx_;                                                    \
+            tfl_ = (2 * ty_ + 1 < H ? 1 : 0) | (2 * tx_ + 1 < W ? 2 : 0);                                \
+            const unsigned rowok_ = (ty_ > 0 ? 1u : 0u) | 2u | (2 * ty_ + 1 < H ? 4u : 0u) | (2 * ty_ + 2 < H ? 8u : 0u); \
+            const unsigned colok_ = (tx_ > 0 ? 1u : 0u) | 2u | (2 * tx_ + 1 < W ? 4u : 0u) | (2 * tx_ + 2 < W ? 8u : 0u); \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) VMASK_ |= ((rowok_ >> i_) & 1u) ? colok_ << (4 * i_) : 0u; \
+        }                                                                                                \
+        if (cp == 0 && ph == 0) {                                                                        \
+            tbl[(TB_) * 128 + 2 * t_ld] = tpx_;                                                          \
+            tbl[(TB_) * 128 + 2 * t_ld + 1] = tfl_;                                                      \
+        }                                                                                                \
+    }
+    // descriptors of a unit: its window's image (one row and one column early, so every valid tap has a
+    // non-negative offset) and its N tile's U image
+#define W8_DESCRIPTORS(BN_, B0_)                                                                         \
+    {                                                                                                    \
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (((long long)(B0_) * H - 1) * W - 1) * (long long)Cin), 0, 0x40000000, 0x00020000); \
+        const unsigned long long ub_ = (unsigned long long)(up + (size_t)(BN_) * KC * WF_POS);           \
+        rsU.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub_);                                      \
+        rsU.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub_ >> 32) & 0xFFFF);                     \
     }
     const int KC = Cin / WF_BK;
-    const unsigned long long ub = (unsigned long long)(up + (size_t)bn * KC * WF_POS);
+    __amdgpu_buffer_rsrc_t rsA;
     i32x4 rsU;
-    rsU.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub);
-    rsU.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32) & 0xFFFF);
     rsU.z = 0x7FFFFFFF;
     rsU.w = 0x00020000;
     const unsigned us_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(Us + sub * (WF_POS / 4)));
@@ -85,11 +108,19 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 
     f32x2 d[16];
     unsigned vo[16];
-#pragma unroll
-    for (int ij = 0; ij < 16; ij++)
-        vo[ij] = ((vmask >> ij) & 1u) ? voff + 4u * (unsigned)(((ij >> 2) * W + (ij & 3)) * Cin) : OOB;
+#define W8_OFFSETS(VOFF_, VMASK_)                                                                        \
+    _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++)                                                 \
+        vo[ij_] = (((VMASK_) >> ij_) & 1u) ? (VOFF_) + 4u * (unsigned)(((ij_ >> 2) * W + (ij_ & 3)) * Cin) : OOB;
+    // first staging of a unit: parity 0 DMAs U chunk 0 into Us[0], every parity loads its first V chunk (0 / 1)
+#define W8_FIRST_LOADS()                                                                                 \
+    {                                                                                                    \
+        if (ph == 0) {                                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) W8_DMA_U1(0, 0, i_)                         \
+        }                                                                                                \
+        _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++) W8_LOAD_V1(ph, ij_)   /* KC >= 2 */          \
+    }
 #define W8_LOAD_V1(KC_, IJ_) d[IJ_] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, vo[IJ_], 4 * (KC_) * WF_BK, 0));
-#define W8_DMA_U1(KC_, BUF_, I_) lds_dma_b128(rsU, uvoff, (KC_) * (WF_POS * 4) + (I_) * 1024, us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024));
+#define W8_DMA_U1(KC_, BUF_, I_) lds_dma_b128(rsU, uvoff, __builtin_amdgcn_readfirstlane((KC_) * (WF_POS * 4) + (I_) * 1024), __builtin_amdgcn_readfirstlane(us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024)));
 #define W8_ROWS()                                                                                        \
     {                                                                                                    \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                                                 \
@@ -121,35 +152,6 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         else                                                                                             \
             bf[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(Us + (BUF_) * WF_POS + rd_u + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)); \
     }
-
-    // ---- prologue: parity 0 stages chunk 0, parity 1 loads chunk 1 ----
-    WF_STAMP(1)
-    if (ph == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) W8_DMA_U1(0, 0, i)
-    }
-    {
-        const int c_ = ph;   // KC >= 2
-#pragma unroll
-        for (int ij = 0; ij < 16; ij++) W8_LOAD_V1(c_, ij)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int p = 0; p < 8; p++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[p][e] = 0.0f;
-    __builtin_amdgcn_sched_barrier(0);
-    if (ph == 0) {
-        W8_ROWS()
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-#pragma unroll
-    for (int qq = 0; qq < 4; qq++) W8_READ_OP(0, 0, 0, qq)
 
     // K step: 32 slots of one MFMA (4 groups g of two positions x 4 k-pairs), each closed by a full
     // scheduling barrier.  Slots 0-3 of a group read the next group's operands (g = 3: after the
@@ -189,77 +191,130 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         cur ^= 1;                                                                                        \
     }
 
-    WF_STAMP(2)
-    int cur = 0;
-    if (ph == 0) {
-        for (int kc = 0; kc < KC; kc += 2) {   // KC is even
-            W8_KSTEP(0)
-            kc++;
-            W8_KSTEP(1)
-            kc--;
-        }
-    } else {
-        for (int kc = 0; kc < KC; kc += 2) {
-            W8_KSTEP(1)
-            kc++;
-            W8_KSTEP(0)
-            kc--;
-        }
+
+    int bn, b0, tb = 0;
+    {
+        unsigned voff, vmask;
+        W8_SETUP(x_start + lidl, 0, bn, b0, voff, vmask)
+        W8_DESCRIPTORS(bn, b0)
+        W8_OFFSETS(voff, vmask)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    WF_STAMP(3)
+    WF_STAMP(1)
+    W8_FIRST_LOADS()
+
+    for (;;) {
+        // ---- prologue of a unit: its first loads are already in flight (issued above, or before the previous
+        //      unit's epilogue); clear the accumulators under their latency, parity 0 stages chunk 0 ----
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[p][e] = 0.0f;
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph == 0) {
+            W8_ROWS()
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) W8_READ_OP(0, 0, 0, qq)
+
+        WF_STAMP(2)
+        int cur = 0;
+        if (ph == 0) {
+            for (int kc = 0; kc < KC; kc += 2) {   // KC is even
+                W8_KSTEP(0)
+                kc++;
+                W8_KSTEP(1)
+                kc--;
+            }
+        } else {
+            for (int kc = 0; kc < KC; kc += 2) {
+                W8_KSTEP(1)
+                kc++;
+                W8_KSTEP(0)
+                kc--;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WF_STAMP(3)
+
+        // ---- the next unit's set-up and first loads go out before this unit's epilogue: d[] and vo[] are free,
+        //      Us[0] was last read a K step ago, the tile table has a second copy ----
+        const int nl = lidl + per;
+        const bool more = nl < x_count;             // workgroup-uniform
+        int bn_n = 0, b0_n = 0;
+        if (more) {
+            unsigned voff, vmask;
+            W8_SETUP(x_start + nl, tb ^ 1, bn_n, b0_n, voff, vmask)
+            W8_DESCRIPTORS(bn_n, b0_n)
+            W8_OFFSETS(voff, vmask)
+            W8_FIRST_LOADS()
+        }
+
+        // ---- epilogue.  acc[q][e]: position ph*8 + q = row 2 ph + q/4, column q%4 of the 4x4 m; e -> tile row
+        //      (e&3) + 8*(e>>2) + 4*(lane>>5), lane&31 -> channel.  A^T = [1 1 1 0; 0 1 -1 -1].
+        //      partial outputs of this wave's two m rows; the pair swaps halves through LDS:
+        //      parity 0 finishes pixels (0,0),(0,1), parity 1 finishes (1,0),(1,1) ----
+        float *xw = Vs + ((sub * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [e][lane][2]
+        const float *xr = Vs + ((sub * 2 + (ph ^ 1)) * 16) * 128 + lane * 2;   // what it receives
+        float keep[16][2];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (ph == 0) { t0[j] = acc[j][e] + acc[4 + j][e]; t1[j] = acc[4 + j][e]; }
+                else { t0[j] = acc[j][e]; t1[j] = -acc[j][e] - acc[4 + j][e]; }
+            }
+            const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
+            const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
+            f32x2 give;
+            if (ph == 0) { keep[e][0] = y00; keep[e][1] = y01; give.x = y10; give.y = y11; }
+            else { keep[e][0] = y10; keep[e][1] = y11; give.x = y00; give.y = y01; }
+            *reinterpret_cast<f32x2 *>(xw + e * 128) = give;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const int n = bn * WF_BN + wn * 32 + li;
+        const float bv = bias[n];
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
+        const unsigned nb4 = 4u * (unsigned)n;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const int px = tbl[tb * 128 + 2 * tl], fl = tbl[tb * 128 + 2 * tl + 1];
+            const f32x2 got = *reinterpret_cast<const f32x2 *>(xr + e * 128);
+            // parity 0 adds the partner's rows 2,3 to its rows 0,1; parity 1 the other way round: same order of
+            // addition for both pixels of a row pair ((rows 0,1) + (rows 2,3))
+            const float ya = fmaxf((ph == 0 ? keep[e][0] + got.x : got.x + keep[e][0]) + bv, 0.0f);
+            const float yb = fmaxf((ph == 0 ? keep[e][1] + got.y : got.y + keep[e][1]) + bv, 0.0f);
+            const unsigned o0 = 4u * (unsigned)(px * Cout) + nb4;
+            const bool rowok = px >= 0 && (ph == 0 || (fl & 1));
+            const unsigned orow = o0 + (ph ? 4u * (unsigned)(W * Cout) : 0u);
+            wf_store1(rsO, rowok ? orow : OOB, ya);
+            wf_store1(rsO, rowok && (fl & 2) ? orow + 4u * (unsigned)Cout : OOB, yb);
+        }
+        WF_STAMP(4)
+        if (!more) break;
+        __syncthreads();    // every wave has read its half of the exchange: Vs may be staged again
+        bn = bn_n; b0 = b0_n; tb ^= 1; lidl = nl;
+    }
+    WF_STAMP(5)
 #undef W8_KSTEP
 #undef W8_READ_OP
 #undef W8_LOAD_V1
 #undef W8_DMA_U1
 #undef W8_ROWS
 #undef W8_STORE_POS
-
-    // ---- epilogue.  acc[q][e]: position ph*8 + q = row 2 ph + q/4, column q%4 of the 4x4 m; e -> tile row
-    //      (e&3) + 8*(e>>2) + 4*(lane>>5), lane&31 -> channel.  A^T = [1 1 1 0; 0 1 -1 -1].
-    //      partial outputs of this wave's two m rows; the pair swaps halves through LDS:
-    //      parity 0 finishes pixels (0,0),(0,1), parity 1 finishes (1,0),(1,1) ----
-    float *xw = Vs + ((sub * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [e][lane][2]
-    const float *xr = Vs + ((sub * 2 + (ph ^ 1)) * 16) * 128 + lane * 2;   // what it receives
-    float keep[16][2];
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        float t0[4], t1[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (ph == 0) { t0[j] = acc[j][e] + acc[4 + j][e]; t1[j] = acc[4 + j][e]; }
-            else { t0[j] = acc[j][e]; t1[j] = -acc[j][e] - acc[4 + j][e]; }
-        }
-        const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
-        const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-        f32x2 give;
-        if (ph == 0) { keep[e][0] = y00; keep[e][1] = y01; give.x = y10; give.y = y11; }
-        else { keep[e][0] = y10; keep[e][1] = y11; give.x = y00; give.y = y01; }
-        *reinterpret_cast<f32x2 *>(xw + e * 128) = give;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    const int n = bn * WF_BN + wn * 32 + li;
-    const float bv = bias[n];
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
-    const unsigned nb4 = 4u * (unsigned)n;
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int px = tbl[2 * tl], fl = tbl[2 * tl + 1];
-        const f32x2 got = *reinterpret_cast<const f32x2 *>(xr + e * 128);
-        // parity 0 adds the partner's rows 2,3 to its rows 0,1; parity 1 the other way round: same order of
-        // addition for both pixels of a row pair ((rows 0,1) + (rows 2,3))
-        const float ya = fmaxf((ph == 0 ? keep[e][0] + got.x : got.x + keep[e][0]) + bv, 0.0f);
-        const float yb = fmaxf((ph == 0 ? keep[e][1] + got.y : got.y + keep[e][1]) + bv, 0.0f);
-        const unsigned o0 = 4u * (unsigned)(px * Cout) + nb4;
-        const bool rowok = px >= 0 && (ph == 0 || (fl & 1));
-        const unsigned orow = o0 + (ph ? 4u * (unsigned)(W * Cout) : 0u);
-        wf_store1(rsO, rowok ? orow : OOB, ya);
-        wf_store1(rsO, rowok && (fl & 2) ? orow + 4u * (unsigned)Cout : OOB, yb);
-    }
-    WF_STAMP(4)
-    WF_STAMP(5)
+#undef W8_SETUP
+#undef W8_DESCRIPTORS
+#undef W8_OFFSETS
+#undef W8_FIRST_LOADS
 }
 
 }  // namespace apr

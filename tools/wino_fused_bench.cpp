@@ -69,10 +69,12 @@ int main(int argc, char **argv)
     const int tiles_n = Cout / apr::WF_BN;
     const long long tiles_m = (T + apr::WF_TT - 1) / apr::WF_TT;
     const bool k8 = getenv("WF8") != nullptr;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(apr::wino_fused8_f2), hipFuncAttributeMaxDynamicSharedMemorySize, apr::WF_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(apr::wino_fused8_f2), hipFuncAttributeMaxDynamicSharedMemorySize, apr::WF8_LDS_BYTES));
+    int n_cus = 256;
+    (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, 0);
     auto launch = [&]() {
         if (k8)
-            hipLaunchKernelGGL(apr::wino_fused8_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(512), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw));
+            hipLaunchKernelGGL(apr::wino_fused8_f2, dim3(apr::wf8_grid((int)(tiles_m * tiles_n), n_cus)), dim3(512), apr::WF8_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw), (int)(tiles_m * tiles_n));
         else
         hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw));
     };
