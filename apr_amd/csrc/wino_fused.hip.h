@@ -51,6 +51,28 @@ __device__ __forceinline__ f32x2 wf_sub2(f32x2 a, f32x2 b)
 #endif
 }
 
+// -a - b
+__device__ __forceinline__ f32x2 wf_nadd2(f32x2 a, f32x2 b)
+{
+#if APR_WF_PK
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[1,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return -a - b;
+#endif
+}
+// max(x, 0) as one instruction (fmaxf on a value out of inline asm costs a canonicalising v_max first); the sums
+// that reach it are never NaN-signalling, and v_max_f32 returns the other operand for a NaN like fmaxf
+__device__ __forceinline__ float wf_relu(float x)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 #ifndef APR_WF_STORE_AUX
 #define APR_WF_STORE_AUX 0   // 2 = nt (streaming) measured neutral here
 #endif

@@ -21,7 +21,11 @@
 
 namespace apr {
 
-constexpr int WF8_LDS_BYTES = 2 * 2 * WF_POS * 4 + 2 * WF_TT * 8;   // Vs[2], Us[2], two tile tables
+#ifndef W8_ABL
+#define W8_ABL 0   // developer timing ablations (tools/wino_fused_bench.cpp): 1 no patch loads, 2 no transform/stores, 4 no U DMA, 8 no barrier
+#endif
+
+constexpr int WF8_LDS_BYTES = 2 * 2 * WF_POS * 4 + 2 * WF_TT * 16;   // Vs[2], Us[2], two tile tables
 
 // grid of the persistent kernel: one workgroup per CU, a multiple of 8 (one share per XCD), no more than the units need
 inline unsigned wf8_grid(int n_units, int n_cus)
@@ -38,9 +42,11 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) float wf_smem[];
     float *Vs = wf_smem;                        // [2][WF_POS]; after the K loop: the pairs' exchange buffers
     float *Us = wf_smem + 2 * WF_POS;           // [2][WF_POS]
-    int *tbl = reinterpret_cast<int *>(wf_smem + 4 * WF_POS);   // [2][64][2]: output pixel of (b, 2ty, 2tx) or -1; flags (one table per unit in flight)
+    unsigned *tbl = reinterpret_cast<unsigned *>(wf_smem + 4 * WF_POS);   // [2][64][4]: byte offsets of a tile's four output pixels (channel 0), out of range if absent (one table per unit in flight)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = tid >> 6;
+    const int phs = __builtin_amdgcn_readfirstlane(wave & 1);    // ph as a scalar: the epilogue branches on it instead of selecting per lane
     const int ph = wave & 1;                    // which 8 of the 16 positions; also the staging parity
     const int sub = wave >> 1;                  // the pair: 2 (tiles) x 2 (channels)
     const int wm = sub >> 1, wn = sub & 1;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         const int g0_ = bm_ * WF_TT;                                                                     \
         B0_ = wf_div(g0_, mg.tpw);                                                                       \
         VOFF_ = OOB; VMASK_ = 0;                                                                         \
-        int tpx_ = -1, tfl_ = 0;                                                                         \
+        u32x4 to_ = {OOB, OOB, OOB, OOB};                                                                \
         const int g_ = g0_ + t_ld;                                                                       \
         if (g_ < T) {                                                                                    \
             const int rr_ = wf_div(g_, mg.tw);                                                           \
@@ -78,16 +84,17 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
             const int db_ = bb_ - B0_;                                                                   \
             const int y0_ = 2 * ty_ - 1, x0_ = 2 * tx_ - 1;                                              \
             VOFF_ = 4u * (unsigned)(((db_ * H + y0_ + 1) * W + x0_ + 1) * Cin + 2 * cp);                 \
-            tpx_ = (db_ * H + 2 * ty_) * W + 2 * tx_;                                                    \
-            tfl_ = (2 * ty_ + 1 < H ? 1 : 0) | (2 * tx_ + 1 < W ? 2 : 0);                                \
+            const unsigned o00_ = 4u * (unsigned)(((db_ * H + 2 * ty_) * W + 2 * tx_) * Cout);           \
+            const bool r1_ = 2 * ty_ + 1 < H, c1_ = 2 * tx_ + 1 < W;                                     \
+            to_.x = o00_;                                                                                \
+            to_.y = c1_ ? o00_ + 4u * (unsigned)Cout : OOB;                                              \
+            to_.z = r1_ ? o00_ + 4u * (unsigned)(W * Cout) : OOB;                                        \
+            to_.w = r1_ && c1_ ? o00_ + 4u * (unsigned)((W + 1) * Cout) : OOB;                           \
             const unsigned rowok_ = (ty_ > 0 ? 1u : 0u) | 2u | (2 * ty_ + 1 < H ? 4u : 0u) | (2 * ty_ + 2 < H ? 8u : 0u); \
             const unsigned colok_ = (tx_ > 0 ? 1u : 0u) | 2u | (2 * tx_ + 1 < W ? 4u : 0u) | (2 * tx_ + 2 < W ? 8u : 0u); \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) VMASK_ |= ((rowok_ >> i_) & 1u) ? colok_ << (4 * i_) : 0u; \
         }                                                                                                \
-        if (cp == 0 && ph == 0) {                                                                        \
-            tbl[(TB_) * 128 + 2 * t_ld] = tpx_;                                                          \
-            tbl[(TB_) * 128 + 2 * t_ld + 1] = tfl_;                                                      \
-        }                                                                                                \
+        if (cp == 0 && ph == 0) *reinterpret_cast<u32x4 *>(tbl + (TB_) * 256 + 4 * t_ld) = to_;          \
     }
     // descriptors of a unit: its window's image (one row and one column early, so every valid tap has a
     // non-negative offset) and its N tile's U image
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         if (ph == 0) {                                                                                   \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) W8_DMA_U1(0, 0, i_)                         \
         }                                                                                                \
-        _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++) W8_LOAD_V1(ph, ij_)   /* KC >= 2 */          \
+        _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++) W8_LOAD_V1(phs, ij_)  /* KC >= 2 */          \
     }
 #define W8_LOAD_V1(KC_, IJ_) d[IJ_] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, vo[IJ_], 4 * (KC_) * WF_BK, 0));
 #define W8_DMA_U1(KC_, BUF_, I_) lds_dma_b128(rsU, uvoff, __builtin_amdgcn_readfirstlane((KC_) * (WF_POS * 4) + (I_) * 1024), __builtin_amdgcn_readfirstlane(us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024)));
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     const int rd_u = (ph * 8) * (64 * WF_BK) + (wn * 32 + li) * WF_BK + rd_sw;
 
     f32x16 acc[8];
+    const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x4 af[2][2], bf[2][2];
 #define W8_READ_OP(SET_, BUF_, G_, Q_)                                                                   \
     {                                                                                                    \
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     //                    U(kc+1) DMA, one piece per slot from slot 1; groups 1-2 the column transform + LDS
     //                    store, one row (four positions) per fourth slot; before the barrier vmcnt(0)
     // Chunk indices past the end are clamped (staging nobody reads).
-#define W8_KSTEP(ROLE)                                                                                   \
+#define W8_KSTEP(ROLE, FIRST)                                                                                 \
     {                                                                                                    \
         const int kn1 = kc + 1 < KC ? kc + 1 : KC - 1;                                                   \
         const int kn2 = kc + 2 < KC ? kc + 2 : KC - 1;                                                   \
@@ -172,19 +180,19 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
                 const int sl = 8 * g + i;                                                                \
                 if (g == 3 && i == 0) {                                                                  \
                     if (ROLE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-                    __syncthreads();                                                                     \
+                    if (!(W8_ABL & 8)) __syncthreads();                                                  \
                 }                                                                                        \
                 if (i < 4) {                                                                             \
                     if (g < 3) W8_READ_OP((g + 1) & 1, cur, g + 1, i)                                    \
                     else W8_READ_OP(0, cur ^ 1, 0, i)                                                    \
                 }                                                                                        \
-                if (ROLE == 0 && sl < 16) W8_LOAD_V1(kn2, sl)                                            \
-                if (ROLE == 1 && sl == 0) W8_ROWS()                                                      \
-                if (ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(kn1, cur ^ 1, sl - 1)                     \
-                if (ROLE == 1 && sl >= 10 && sl <= 22 && ((sl - 10) & 3) == 0) {                         \
+                if (!(W8_ABL & 1) && ROLE == 0 && sl < 16) W8_LOAD_V1(kn2, sl)                           \
+                if (!(W8_ABL & 2) && ROLE == 1 && sl == 0) W8_ROWS()                                     \
+                if (!(W8_ABL & 4) && ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(kn1, cur ^ 1, sl - 1)    \
+                if (!(W8_ABL & 2) && ROLE == 1 && sl >= 10 && sl <= 22 && ((sl - 10) & 3) == 0) {        \
                     _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) W8_STORE_POS(cur ^ 1, (sl - 10) >> 2, q_) \
                 }                                                                                        \
-                acc[2 * g + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i & 1][i >> 1], bf[g & 1][i & 1][i >> 1], acc[2 * g + (i & 1)], 0, 0, 0); \
+                acc[2 * g + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i & 1][i >> 1], bf[g & 1][i & 1][i >> 1], (FIRST) && i < 2 ? zero16 : acc[2 * g + (i & 1)], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
             }                                                                                            \
         }                                                                                                \
@@ -199,25 +207,23 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         W8_DESCRIPTORS(bn, b0)
         W8_OFFSETS(voff, vmask)
     }
-    WF_STAMP(1)
     W8_FIRST_LOADS()
-
     for (;;) {
+        WF_STAMP(1)
+        // this unit's bias, now: a load issued in the epilogue would be younger than the next unit's patch loads and
+        // its wait would cover them
+        const int n = bn * WF_BN + wn * 32 + li;
+        const float bv = bias[n];
+        __builtin_amdgcn_sched_barrier(0);
         // ---- prologue of a unit: its first loads are already in flight (issued above, or before the previous
-        //      unit's epilogue); clear the accumulators under their latency, parity 0 stages chunk 0 ----
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int p = 0; p < 8; p++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[p][e] = 0.0f;
-        __builtin_amdgcn_sched_barrier(0);
+        //      unit's epilogue); parity 0 stages chunk 0 ----
         if (ph == 0) {
             W8_ROWS()
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the U DMA has landed
         }
         __syncthreads();
 #pragma unroll
@@ -225,22 +231,37 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 
         WF_STAMP(2)
         int cur = 0;
+        // the first step's first MFMA of every accumulator takes C = 0: no clearing pass (128 v_mov a wave)
         if (ph == 0) {
-            for (int kc = 0; kc < KC; kc += 2) {   // KC is even
-                W8_KSTEP(0)
+            {
+                int kc = 0;
+                W8_KSTEP(0, true)
+                kc = 1;
+                W8_KSTEP(1, false)
+            }
+            for (int kc = 2; kc < KC; kc += 2) {   // KC is even
+                W8_KSTEP(0, false)
                 kc++;
-                W8_KSTEP(1)
+                W8_KSTEP(1, false)
                 kc--;
             }
         } else {
-            for (int kc = 0; kc < KC; kc += 2) {
-                W8_KSTEP(1)
+            {
+                int kc = 0;
+                W8_KSTEP(1, true)
+                kc = 1;
+                W8_KSTEP(0, false)
+            }
+            for (int kc = 2; kc < KC; kc += 2) {
+                W8_KSTEP(1, false)
                 kc++;
-                W8_KSTEP(0)
+                W8_KSTEP(0, false)
                 kc--;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        f32x2 bv2 = {bv, bv};
+        asm volatile("" : "+v"(bv2));   // hipcc's own wait for the bias load goes here, where nothing is in flight
         WF_STAMP(3)
 
         // ---- the next unit's set-up and first loads go out before this unit's epilogue: d[] and vo[] are free,
@@ -255,56 +276,63 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
             W8_OFFSETS(voff, vmask)
             W8_FIRST_LOADS()
         }
+        WF_STAMP(4)
 
         // ---- epilogue.  acc[q][e]: position ph*8 + q = row 2 ph + q/4, column q%4 of the 4x4 m; e -> tile row
         //      (e&3) + 8*(e>>2) + 4*(lane>>5), lane&31 -> channel.  A^T = [1 1 1 0; 0 1 -1 -1].
         //      partial outputs of this wave's two m rows; the pair swaps halves through LDS:
         //      parity 0 finishes pixels (0,0),(0,1), parity 1 finishes (1,0),(1,1) ----
-        float *xw = Vs + ((sub * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [e][lane][2]
+        float *xw = Vs + ((sub * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [2 ep + column][lane][2]
         const float *xr = Vs + ((sub * 2 + (ph ^ 1)) * 16) * 128 + lane * 2;   // what it receives
-        float keep[16][2];
-#pragma unroll
-        for (int e = 0; e < 16; e++) {
-            float t0[4], t1[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (ph == 0) { t0[j] = acc[j][e] + acc[4 + j][e]; t1[j] = acc[4 + j][e]; }
-                else { t0[j] = acc[j][e]; t1[j] = -acc[j][e] - acc[4 + j][e]; }
-            }
-            const float y00 = t0[0] + t0[1] + t0[2], y01 = t0[1] - t0[2] - t0[3];
-            const float y10 = t1[0] + t1[1] + t1[2], y11 = t1[1] - t1[2] - t1[3];
-            f32x2 give;
-            if (ph == 0) { keep[e][0] = y00; keep[e][1] = y01; give.x = y10; give.y = y11; }
-            else { keep[e][0] = y10; keep[e][1] = y11; give.x = y00; give.y = y01; }
-            *reinterpret_cast<f32x2 *>(xw + e * 128) = give;
-            __builtin_amdgcn_sched_barrier(0);
+        // two tile rows (e = 2 ep, 2 ep + 1: neighbouring accumulator registers) per packed instruction
+        f32x2 keep[8][2];
+        // PH_ is a literal: two straight-line copies, chosen once by the (scalar) parity
+#define W8_EPI_FIRST(PH_)                                                                                \
+        _Pragma("unroll") for (int ep = 0; ep < 8; ep++)                                                 \
+        {                                                                                                \
+            f32x2 t0[4], t1[4];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 4; j++)                                                \
+            {                                                                                            \
+                const f32x2 a = {acc[j][2 * ep], acc[j][2 * ep + 1]};                                    \
+                const f32x2 b = {acc[4 + j][2 * ep], acc[4 + j][2 * ep + 1]};                            \
+                if ((PH_) == 0) { t0[j] = wf_add2(a, b); t1[j] = b; }                                    \
+                else { t0[j] = a; t1[j] = wf_nadd2(a, b); }                                              \
+            }                                                                                            \
+            const f32x2 y00 = wf_add2(wf_add2(t0[0], t0[1]), t0[2]), y01 = wf_sub2(wf_sub2(t0[1], t0[2]), t0[3]); \
+            const f32x2 y10 = wf_add2(wf_add2(t1[0], t1[1]), t1[2]), y11 = wf_sub2(wf_sub2(t1[1], t1[2]), t1[3]); \
+            keep[ep][0] = (PH_) == 0 ? y00 : y10;                                                        \
+            keep[ep][1] = (PH_) == 0 ? y01 : y11;                                                        \
+            *reinterpret_cast<f32x2 *>(xw + (2 * ep) * 128) = (PH_) == 0 ? y10 : y00;                    \
+            *reinterpret_cast<f32x2 *>(xw + (2 * ep + 1) * 128) = (PH_) == 0 ? y11 : y01;                \
+            __builtin_amdgcn_sched_barrier(0);                                                           \
         }
+        if (phs == 0) { W8_EPI_FIRST(0) } else { W8_EPI_FIRST(1) }
+#undef W8_EPI_FIRST
         __syncthreads();
-        const int n = bn * WF_BN + wn * 32 + li;
-        const float bv = bias[n];
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
         const unsigned nb4 = 4u * (unsigned)n;
+        // parity 0 finishes the tile's pixels (0,0), (0,1), parity 1 (1,0), (1,1): its half of the tile's table row
+        const unsigned *tp = tbl + tb * 256 + (wm * 32 + 4 * half) * 4 + 2 * ph;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const int tl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            const int px = tbl[tb * 128 + 2 * tl], fl = tbl[tb * 128 + 2 * tl + 1];
-            const f32x2 got = *reinterpret_cast<const f32x2 *>(xr + e * 128);
-            // parity 0 adds the partner's rows 2,3 to its rows 0,1; parity 1 the other way round: same order of
-            // addition for both pixels of a row pair ((rows 0,1) + (rows 2,3))
-            const float ya = fmaxf((ph == 0 ? keep[e][0] + got.x : got.x + keep[e][0]) + bv, 0.0f);
-            const float yb = fmaxf((ph == 0 ? keep[e][1] + got.y : got.y + keep[e][1]) + bv, 0.0f);
-            const unsigned o0 = 4u * (unsigned)(px * Cout) + nb4;
-            const bool rowok = px >= 0 && (ph == 0 || (fl & 1));
-            const unsigned orow = o0 + (ph ? 4u * (unsigned)(W * Cout) : 0u);
-            wf_store1(rsO, rowok ? orow : OOB, ya);
-            wf_store1(rsO, rowok && (fl & 2) ? orow + 4u * (unsigned)Cout : OOB, yb);
+        for (int ep = 0; ep < 8; ep++) {
+            const f32x2 g0 = *reinterpret_cast<const f32x2 *>(xr + (2 * ep) * 128);
+            const f32x2 g1 = *reinterpret_cast<const f32x2 *>(xr + (2 * ep + 1) * 128);
+            // (rows 0,1) + (rows 2,3), then the bias: the order of wino_fused_f2
+            const f32x2 ya = wf_add2(wf_add2(keep[ep][0], g0), bv2);
+            const f32x2 yb = wf_add2(wf_add2(keep[ep][1], g1), bv2);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int e = 2 * ep + h;
+                const u32x2 o = *reinterpret_cast<const u32x2 *>(tp + ((e & 3) + 8 * (e >> 2)) * 4);   // absent pixels stay out of range
+                wf_store1(rsO, o.x + nb4, wf_relu(h ? ya.y : ya.x));
+                wf_store1(rsO, o.y + nb4, wf_relu(h ? yb.y : yb.x));
+            }
         }
-        WF_STAMP(4)
+        WF_STAMP(5)
         if (!more) break;
         __syncthreads();    // every wave has read its half of the exchange: Vs may be staged again
         bn = bn_n; b0 = b0_n; tb ^= 1; lidl = nl;
     }
-    WF_STAMP(5)
 #undef W8_KSTEP
 #undef W8_READ_OP
 #undef W8_LOAD_V1

@@ -37,7 +37,7 @@ def main() -> int:
     ap.add_argument("--files", type=int, default=60, help="recordings per GPU")
     ap.add_argument("--seconds", type=int, default=600, help="seconds per recording")
     ap.add_argument("--max-batch", type=int, default=2048, help="windows per GPU pass")
-    ap.add_argument("--cpu-windows", type=int, default=96, help="windows of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=599, help="windows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed sweep: no classifier centring, latency probe or CPU baseline "
@@ -78,7 +78,8 @@ def main() -> int:
     # centre the random-init classifier on this data so that labels vary between windows
     if not args.no_extras:
         eng0 = model.Engine(W.pack_blob(flat, C), local_rank, 64)
-        cal = eng0.infer_logits(eng0.prepare_batch(pcm_host[:48000 * 65], 64))
+        # (recording 0 on every rank, so that all ranks score with identical weights)
+        cal = eng0.infer_logits(eng0.prepare_batch(model.synth_pcm(0, 0, 65), 64))
         eng0.close()
         flat = W.center_logits(flat, C, cal.mean(axis=0))
     eng = model.Engine(W.pack_blob(flat, C), local_rank, args.max_batch)
