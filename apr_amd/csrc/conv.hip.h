@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     if (MODE == 1) {                                 // batched GEMM: this block's problem
         in += (size_t)blockIdx.y * M * Cin;
         wt += (size_t)blockIdx.y * Cin * Cout;
-        out += (size_t)blockIdx.y * M * Cout;
+        out += ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * M * Cout;   // gridDim.z > 1: this K split's copy of M[16][T][Cout]
     }
     if (MODE == 2) out += (size_t)blockIdx.y * M * Cout;   // this split's partial sums
     // descriptor base = one row and one column before window b0's image, so every valid
@@ -231,8 +231,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const int cchunks = Cin / BK;
     const int KT = TAPS * cchunks;
     // K steps of this block: all of them, or this split's share (gridDim.y <= KT, host-checked)
-    const int kt0 = MODE == 2 ? (int)(((long long)KT * blockIdx.y) / gridDim.y) : 0;
-    const int kt1 = MODE == 2 ? (int)(((long long)KT * (blockIdx.y + 1)) / gridDim.y) : KT;
+    // (MODE 1: the split is blockIdx.z, one-clip engines only; wino_output_f2 adds the copies in split order)
+    const int ks = MODE == 2 ? (int)blockIdx.y : MODE == 1 ? (int)blockIdx.z : 0;
+    const int kn = MODE == 2 ? (int)gridDim.y : MODE == 1 ? (int)gridDim.z : 1;
+    const int kt0 = (int)(((long long)KT * ks) / kn);
+    const int kt1 = (int)(((long long)KT * (ks + 1)) / kn);
 
     f32x4 ra[AROWS], rb[BPASS];
     // K order for Cin >= 128: (tap row dy, channel chunk, tap column dx).  The three dx taps of one 64-B
@@ -396,7 +399,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         f32x4 a = *reinterpret_cast<const f32x4 *>(bias + 4 * (i % cout4));
-        for (int s = 0; s < nsplit; s++) a += *reinterpret_cast<const f32x4 *>(part + 4 * (s * n4 + i));
+        // eight partials in flight at a time (a one-clip grid is a few workgroups: a chain of dependent loads was 64 L2
+        // latencies long); the additions stay in split order
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int s = s0 + u < nsplit ? s0 + u : nsplit - 1;
+                v[u] = *reinterpret_cast<const f32x4 *>(part + 4 * (s * n4 + i));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (s0 + u < nsplit) a += v[u];
+        }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4 *>(out + 4 * i) = __builtin_elementwise_max(a, zero);
     }
@@ -420,6 +435,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ act
     const float *a = act + win * (long long)P * F;
     for (int c = tid; c < F; c += 256) {
         float m = a[c];
+#pragma unroll 8   // loads in flight together: one clip is one workgroup, and a chain of dependent loads is all it waits for
         for (int p = 1; p < P; p++) m = fmaxf(m, a[(long long)p * F + c]);
         s_feat[c] = m;
     }
@@ -427,6 +443,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ act
     // one wave per class (round-robin): 64-lane strided dot + shuffle reduce
     for (int o = wave; o < C; o += 4) {
         float s = 0.0f;
+#pragma unroll 16   // same fmaf chain, the 16 weight loads issued together
         for (int c = lane; c < F; c += 64) s = fmaf(wfc[(long long)o * F + c], s_feat[c], s);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);

@@ -41,6 +41,7 @@ struct Layer {
     int th = 0, tw = 0;     // 2x2-output tiles per window
     int wbm_tile = 128;
     int ksplit = 1;         // > 1: direct kernel split along K (latency engines), partial sums in d_part
+    int wsplit = 1;         // > 1: the Winograd-domain GEMMs split along K (latency engines), copies of M in d_M
     int slot = -1, slot_in = -1, slot_out = -1;   // profile slots of its kernels (slot_out: also the split-K reduce)
 };
 
@@ -272,7 +273,9 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     const char *fcenv = getenv("APR_WINO_FUSED_MAX_CIN");
     // Cin = 512 (layers 9, 11): the one-kernel form wins once a pass holds enough tiles to fill the chip (measured at
     // 2048 windows: 58.0 vs 67.6 ms and 29.0 vs 31.9 ms a step); small engines keep transform kernels + batched GEMM there
-    const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : 256);
+    // one-clip engines (max_batch <= 4): 24 or 16 work units of layers 5 and 7 leave the chip idle while each walks 16 or 32 K
+    // steps (39.8 and 71.5 us); transform kernels + 16 batched GEMMs spread the same work over 100+ workgroups (25.6 and 31.8 us)
+    const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
         Layer L;
@@ -342,8 +345,15 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             L.tw = (L.wout + 1) / 2;
             const long long t_full = (long long)e->max_batch * L.th * L.tw;
             L.wbm_tile = ((t_full + 127) / 128) * (cv.cout / 128) * 16 < 1024 ? 64 : 128;
+            // one-clip engines: a few dozen workgroups with Cin / 16 K steps each; split K (>= 4 steps a split) towards 512
+            if (splitk_on && e->max_batch <= 4) {
+                const long long blocks = ((t_full + L.wbm_tile - 1) / L.wbm_tile) * (cv.cout / 128) * 16;
+                const char *wsenv = getenv("APR_WSPLIT_MAX");   // developer knob
+                const long long wsmax = wsenv ? atoi(wsenv) : 4;
+                L.wsplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(512 / std::max<long long>(blocks, 1), cv.cin / 16 / 4), wsmax));
+            }
             v_max = std::max(v_max, (size_t)16 * L.th * L.tw * cv.cin);
-            m_max = std::max(m_max, (size_t)16 * L.th * L.tw * cv.cout);
+            m_max = std::max(m_max, (size_t)L.wsplit * 16 * L.th * L.tw * cv.cout);
         }
         act_max = std::max(act_max, (size_t)L.cout * L.hout * L.wout);
         h = L.hout; w = L.wout;
@@ -461,7 +471,7 @@ void launch_wino_gemm(apr_engine *e, const Layer &L, long long T)
 {
     const int tiles_n = L.cout / 128;
     const long long tiles_m = (T + BM - 1) / BM;
-    hipLaunchKernelGGL((conv3x3_igemm_f32<BM, 128, 1, 1>), dim3((unsigned)(tiles_m * tiles_n), 16), dim3(256), 0, e->stream, e->d_V,
+    hipLaunchKernelGGL((conv3x3_igemm_f32<BM, 128, 1, 1>), dim3((unsigned)(tiles_m * tiles_n), 16, (unsigned)L.wsplit), dim3(256), 0, e->stream, e->d_V,
                        L.d_u, L.d_b, e->d_M, 1, 1, L.cin, 1, 1, L.cout, (int)T, tiles_n);
 }
 
@@ -518,7 +528,7 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             {
                 ProfScope ps(e, L.slot_out, 0.0, 4.0 * (16.0 * T * L.cout + (double)M * L.cout));
                 hipLaunchKernelGGL(wino_output_f2, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
-                                   e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
+                                   e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T, L.wsplit);
             }
             in = out;
             continue;

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void db_norm_kernel(const float *__restrict__ 
     // global max over [n_frames][128]
     float mx = 0.0f;
     const int n4 = n_frames * kNmels / 4;
+#pragma unroll 8   // a single clip is one workgroup per column chunk: without the unroll, 23 dependent round trips
     for (int i = tid; i < n4; i += 256) {
         const float4 q = reinterpret_cast<const float4 *>(src)[i];
         mx = fmaxf(mx, fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void wino_input_f2(const float *__restrict__ i
 // M[16][T][C] -> out [B][Ho][Wo][C] with bias + ReLU.  A^T = [1 1 1 0; 0 1 -1 -1].
 __global__ __launch_bounds__(256) void wino_output_f2(const float *__restrict__ Mx, const float *__restrict__ bias,
                                                       float *__restrict__ out, int Ho, int Wo, int C, int th, int tw,
-                                                      long long T)
+                                                      long long T, int nsplit)
 {
     const int c4n = C >> 2;
     const long long total = T * c4n;
@@ -93,6 +93,27 @@ __global__ __launch_bounds__(256) void wino_output_f2(const float *__restrict__ 
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) m[i][j] = ld4(Mx + ((long long)(4 * i + j) * T + t) * C + c);
+        // one-clip engines split the GEMMs along K: copies s >= 1 of M, added in split order
+        //  (two copies' loads in flight at a time: the chain of dependent round trips is what this kernel costs there)
+        for (int s = 1; s < nsplit; s += 2) {
+            const bool two = s + 1 < nsplit;
+            const float *Ma = Mx + (long long)s * 16 * T * C, *Mb = Mx + (long long)(two ? s + 1 : s) * 16 * T * C;
+            f32x4 a[4][4], b[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    a[i][j] = ld4(Ma + ((long long)(4 * i + j) * T + t) * C + c);
+                    b[i][j] = ld4(Mb + ((long long)(4 * i + j) * T + t) * C + c);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    m[i][j] += a[i][j];
+                    if (two) m[i][j] += b[i][j];
+                }
+        }
         // rows: tmp = A^T m  (2 x 4)
         f32x4 tmp[2][4];
 #pragma unroll
