@@ -100,6 +100,19 @@ struct apr_engine {
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     size_t pin_cap = 0;
 
+    // one-clip engines (max_batch <= 4): apr_score replays a captured hipGraph (H2D from pinned staging, every kernel,
+    // D2H into pinned staging) instead of ~30 launches a call; re-captured when the call's shape or decision rule changes
+    bool graph_on = false;
+    hipGraphExec_t sg_exec = nullptr;
+    size_t sg_nw = 0, sg_span = 0, sg_stride = 0;
+    double sg_trust = 0.0;
+    int sg_empty = 0;
+    uint8_t *h_sg_pcm = nullptr;
+    size_t h_sg_cap = 0;
+    double *h_sg_probs = nullptr;
+    int32_t *h_sg_label = nullptr;
+    uint8_t *h_sg_match = nullptr;
+
     // profiling
     bool prof_on = false;
     apr_profile_slot slots[APR_PROF_SLOTS];
@@ -608,6 +621,55 @@ size_t span_bytes(size_t total_bytes, size_t w0, size_t nw, size_t stride)
     return std::min(want, total_bytes - off);
 }
 
+constexpr int kGraphUnavailable = -1000;   // internal: never returned through the C ABI
+// apr_score of a one-clip engine as one graph launch.  kGraphUnavailable = could not capture (the caller falls back).
+int score_graph(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t nw, size_t stride, double trust, int empty_class,
+                double *probs, int32_t *label, uint8_t *match)
+{
+    const int C = e->n_classes;
+    const size_t span = span_bytes(total_bytes, 0, nw, stride);
+    int rc;
+    if ((rc = ensure_staging(e, span))) return rc;
+    if (span > e->h_sg_cap) {
+        if (e->sg_exec) { (void)hipGraphExecDestroy(e->sg_exec); e->sg_exec = nullptr; }
+        if (e->h_sg_pcm) { (void)hipHostFree(e->h_sg_pcm); e->h_sg_pcm = nullptr; e->h_sg_cap = 0; }
+        const size_t cap = std::max(span, (size_t)e->max_batch * APR_BYTES_PER_SECOND + APR_SAMPLE_SIZE);
+        if (hipHostMalloc((void **)&e->h_sg_pcm, cap, hipHostMallocDefault) != hipSuccess) { e->h_sg_pcm = nullptr; return kGraphUnavailable; }
+        e->h_sg_cap = cap;
+    }
+    if (!e->h_sg_probs) {
+        if (hipHostMalloc((void **)&e->h_sg_probs, (size_t)e->max_batch * C * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&e->h_sg_label, (size_t)e->max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&e->h_sg_match, (size_t)e->max_batch, hipHostMallocDefault) != hipSuccess)
+            return kGraphUnavailable;
+    }
+    if (!e->sg_exec || e->sg_nw != nw || e->sg_span != span || e->sg_stride != stride || e->sg_trust != trust || e->sg_empty != empty_class) {
+        if (e->sg_exec) { (void)hipGraphExecDestroy(e->sg_exec); e->sg_exec = nullptr; }
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return kGraphUnavailable;
+        bool ok = true;
+        if (span) ok = hipMemcpyAsync(e->d_pcm, e->h_sg_pcm, span, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && run_frontend(e, APR_FLAVOUR_GO, e->d_pcm, span, (int)nw, stride, e->d_spec) == APR_OK;
+        ok = ok && run_cnn(e, e->d_spec, (int)nw, trust, empty_class, nullptr, e->d_probs, e->d_label, e->d_match) == APR_OK;
+        ok = ok && hipMemcpyAsync(e->h_sg_probs, e->d_probs, nw * C * sizeof(double), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->h_sg_label, e->d_label, nw * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->h_sg_match, e->d_match, nw, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        hipGraph_t g = nullptr;
+        const bool ended = hipStreamEndCapture(e->stream, &g) == hipSuccess && g;
+        if (ok && ended && hipGraphInstantiate(&e->sg_exec, g, nullptr, nullptr, 0) != hipSuccess) e->sg_exec = nullptr;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok || !ended || !e->sg_exec) { e->sg_exec = nullptr; (void)hipGetLastError(); return kGraphUnavailable; }
+        e->sg_nw = nw; e->sg_span = span; e->sg_stride = stride; e->sg_trust = trust; e->sg_empty = empty_class;
+    }
+    if (span) memcpy(e->h_sg_pcm, pcm, span);
+    HIPCHK(e, hipGraphLaunch(e->sg_exec, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (probs) memcpy(probs, e->h_sg_probs, nw * C * sizeof(double));
+    if (label) memcpy(label, e->h_sg_label, nw * sizeof(int32_t));
+    if (match) memcpy(match, e->h_sg_match, nw);
+    return APR_OK;
+}
+
 int check_engine(apr_engine *e)
 {
     if (!e) return APR_ERR_INVALID;
@@ -674,6 +736,10 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         e->err = "could not reserve LDS for conv12_fused_kernel";
         rc = APR_ERR_DEVICE;
     }
+    {
+        const char *genv = getenv("APR_GRAPH");   // APR_GRAPH=0: one-clip engines launch kernel by kernel
+        e->graph_on = e->max_batch <= 4 && !(genv && genv[0] == '0');
+    }
     if (!rc) rc = build_frontend(e);
     if (!rc && has_model) rc = build_cnn(e, pm);
     if (!rc && has_model) {
@@ -727,6 +793,11 @@ void apr_engine_destroy(apr_engine *e)
         if (e->ev_h2d[b]) (void)hipEventDestroy(e->ev_h2d[b]);
         if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
     }
+    if (e->sg_exec) (void)hipGraphExecDestroy(e->sg_exec);
+    if (e->h_sg_pcm) (void)hipHostFree(e->h_sg_pcm);
+    if (e->h_sg_probs) (void)hipHostFree(e->h_sg_probs);
+    if (e->h_sg_label) (void)hipHostFree(e->h_sg_label);
+    if (e->h_sg_match) (void)hipHostFree(e->h_sg_match);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -892,6 +963,11 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
     if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
     if ((total_bytes && !pcm) || (n_windows > 1 && !stride_bytes)) { e->err = "apr_score: bad argument"; return APR_ERR_INVALID; }
     const int C = e->n_classes;
+    if (e->graph_on && !e->prof_on && n_windows >= 1 && n_windows <= (size_t)e->max_batch) {
+        rc = score_graph(e, pcm, total_bytes, n_windows, stride_bytes, trust, empty_class, probs, label, match);
+        if (rc != kGraphUnavailable) return rc;   // capture not available: this engine launches kernel by kernel from now on
+        e->graph_on = false;
+    }
     for (size_t w0 = 0; w0 < n_windows; w0 += (size_t)e->max_batch) {
         const size_t nw = std::min<size_t>(e->max_batch, n_windows - w0);
         const size_t span = span_bytes(total_bytes, w0, nw, stride_bytes);

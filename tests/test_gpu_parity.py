@@ -312,6 +312,24 @@ def test_latency_engine_split_k(he_weights):
     lat.close(); thr.close()
 
 
+def test_one_clip_graph_replay_equals_kernel_by_kernel(he_weights, monkeypatch):
+    # One-clip engines replay apr_score as a captured hipGraph (APR_GRAPH=0: kernel by kernel).  Same kernels,
+    # same order: bit-identical; a change of clip length, trust or empty class re-captures.
+    blob = W.pack_blob(he_weights, 4)
+    g = model.Engine(blob, 0, 1)
+    monkeypatch.setenv("APR_GRAPH", "0")
+    k = model.Engine(blob, 0, 1)
+    monkeypatch.delenv("APR_GRAPH")
+    pcm = model.synth_pcm(11, 3, 8)
+    for sec, nbytes, trust, empty in ((0, 192000, 0.5, 2), (1, 192000, 0.5, 2), (2, 192000, 0.25, 2), (3, 192000, 0.25, 0),
+                                      (4, 100001, 0.25, 0), (5, 192000, 0.25, 0), (6, 0, 0.5, 2)):
+        clip = pcm[sec * 48000:].view(np.uint8)[:nbytes]
+        a = g.score(clip, 1, trust=trust, empty_class=empty)
+        b = k.score(clip, 1, trust=trust, empty_class=empty)
+        assert all(np.array_equal(a[key], b[key]) for key in ("probs", "label", "match")), (sec, nbytes)
+    g.close(); k.close()
+
+
 def test_full_size_sweep_properties(he_weights):
     # BASELINE config 2 at full size (60 recordings x 600 s = 35 999 stream windows on one GPU),
     # checked through size-independent properties + an oracle sample.
