@@ -52,6 +52,16 @@ struct ProfPair {
 
 }  // namespace
 
+struct GraphSlot {
+    hipGraphExec_t exec = nullptr;
+    size_t k0 = 0, k1 = 0, k2 = 0;   // the call shape the graph was captured for
+    double kd = 0.0;
+    int ki = 0;
+};
+constexpr int kGraphWindows = 4;                                        // largest call that is replayed
+constexpr size_t kGraphIn = (size_t)kGraphWindows * APR_SAMPLE_SIZE;    // PCM span or spectrograms of such a call
+constexpr size_t kGraphOut = (size_t)kGraphWindows * APR_SPEC_ELEMS * sizeof(float);
+
 struct apr_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -100,18 +110,12 @@ struct apr_engine {
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
     size_t pin_cap = 0;
 
-    // one-clip engines (max_batch <= 4): apr_score replays a captured hipGraph (H2D from pinned staging, every kernel,
-    // D2H into pinned staging) instead of ~30 launches a call; re-captured when the call's shape or decision rule changes
+    // Calls of at most 4 windows through the host-pointer entry points (apr_score, apr_infer, apr_prepare[_batch]: the
+    // daemon's one-clip-per-call pattern) replay a captured hipGraph -- H2D from pinned staging, every kernel, D2H into
+    // pinned staging -- instead of ~30 launches a call; re-captured when the call's shape or decision rule changes.
     bool graph_on = false;
-    hipGraphExec_t sg_exec = nullptr;
-    size_t sg_nw = 0, sg_span = 0, sg_stride = 0;
-    double sg_trust = 0.0;
-    int sg_empty = 0;
-    uint8_t *h_sg_pcm = nullptr;
-    size_t h_sg_cap = 0;
-    double *h_sg_probs = nullptr;
-    int32_t *h_sg_label = nullptr;
-    uint8_t *h_sg_match = nullptr;
+    GraphSlot g_score, g_infer, g_prep[2];
+    uint8_t *h_g_in = nullptr, *h_g_out = nullptr;   // kGraphIn / kGraphOut bytes, pinned
 
     // profiling
     bool prof_on = false;
@@ -622,51 +626,107 @@ size_t span_bytes(size_t total_bytes, size_t w0, size_t nw, size_t stride)
 }
 
 constexpr int kGraphUnavailable = -1000;   // internal: never returned through the C ABI
-// apr_score of a one-clip engine as one graph launch.  kGraphUnavailable = could not capture (the caller falls back).
-int score_graph(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t nw, size_t stride, double trust, int empty_class,
+
+// Replay (capturing first if the key changed) the stream work that record() issues.  record() may only enqueue work on
+// e->stream (no allocation, no synchronisation) and returns false on any error.  kGraphUnavailable = could not capture:
+// the caller falls back to launching kernel by kernel.
+template <class F>
+int graph_replay(apr_engine *e, GraphSlot &s, size_t k0, size_t k1, size_t k2, double kd, int ki, F record)
+{
+    if (!s.exec || s.k0 != k0 || s.k1 != k1 || s.k2 != k2 || s.kd != kd || s.ki != ki) {
+        if (s.exec) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return kGraphUnavailable; }
+        const bool ok = record();
+        hipGraph_t g = nullptr;
+        const bool ended = hipStreamEndCapture(e->stream, &g) == hipSuccess && g;
+        if (ok && ended && hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0) != hipSuccess) s.exec = nullptr;
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok || !ended || !s.exec) { s.exec = nullptr; (void)hipGetLastError(); return kGraphUnavailable; }
+        s.k0 = k0; s.k1 = k1; s.k2 = k2; s.kd = kd; s.ki = ki;
+    }
+    HIPCHK(e, hipGraphLaunch(s.exec, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return APR_OK;
+}
+
+// pinned staging of the replayed calls (fixed size: the graphs hold its addresses)
+int graph_staging(apr_engine *e)
+{
+    if (e->h_g_in && e->h_g_out) return APR_OK;
+    if ((!e->h_g_in && hipHostMalloc((void **)&e->h_g_in, kGraphIn, hipHostMallocDefault) != hipSuccess) ||
+        (!e->h_g_out && hipHostMalloc((void **)&e->h_g_out, kGraphOut, hipHostMallocDefault) != hipSuccess)) {
+        (void)hipGetLastError();
+        return kGraphUnavailable;
+    }
+    return APR_OK;
+}
+
+// may this call be replayed?  (profiling needs its events between the kernels)
+bool graph_ok(const apr_engine *e, size_t n, size_t in_bytes)
+{
+    return e->graph_on && !e->prof_on && n >= 1 && n <= (size_t)std::min(e->max_batch, kGraphWindows) && in_bytes <= kGraphIn;
+}
+
+// apr_score as one graph launch
+int score_graph(apr_engine *e, const uint8_t *pcm, size_t span, size_t nw, size_t stride, double trust, int empty_class,
                 double *probs, int32_t *label, uint8_t *match)
 {
     const int C = e->n_classes;
-    const size_t span = span_bytes(total_bytes, 0, nw, stride);
     int rc;
-    if ((rc = ensure_staging(e, span))) return rc;
-    if (span > e->h_sg_cap) {
-        if (e->sg_exec) { (void)hipGraphExecDestroy(e->sg_exec); e->sg_exec = nullptr; }
-        if (e->h_sg_pcm) { (void)hipHostFree(e->h_sg_pcm); e->h_sg_pcm = nullptr; e->h_sg_cap = 0; }
-        const size_t cap = std::max(span, (size_t)e->max_batch * APR_BYTES_PER_SECOND + APR_SAMPLE_SIZE);
-        if (hipHostMalloc((void **)&e->h_sg_pcm, cap, hipHostMallocDefault) != hipSuccess) { e->h_sg_pcm = nullptr; return kGraphUnavailable; }
-        e->h_sg_cap = cap;
-    }
-    if (!e->h_sg_probs) {
-        if (hipHostMalloc((void **)&e->h_sg_probs, (size_t)e->max_batch * C * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&e->h_sg_label, (size_t)e->max_batch * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&e->h_sg_match, (size_t)e->max_batch, hipHostMallocDefault) != hipSuccess)
-            return kGraphUnavailable;
-    }
-    if (!e->sg_exec || e->sg_nw != nw || e->sg_span != span || e->sg_stride != stride || e->sg_trust != trust || e->sg_empty != empty_class) {
-        if (e->sg_exec) { (void)hipGraphExecDestroy(e->sg_exec); e->sg_exec = nullptr; }
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return kGraphUnavailable;
+    if ((rc = ensure_staging(e, span)) || (rc = graph_staging(e))) return rc;
+    double *hp = reinterpret_cast<double *>(e->h_g_out);                       // [nw][C] <= 4 * 64 doubles
+    int32_t *hl = reinterpret_cast<int32_t *>(e->h_g_out + 4096);
+    uint8_t *hm = e->h_g_out + 4096 + 64;
+    if (span) memcpy(e->h_g_in, pcm, span);
+    rc = graph_replay(e, e->g_score, nw, span, stride, trust, empty_class, [&]() {
         bool ok = true;
-        if (span) ok = hipMemcpyAsync(e->d_pcm, e->h_sg_pcm, span, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        if (span) ok = hipMemcpyAsync(e->d_pcm, e->h_g_in, span, hipMemcpyHostToDevice, e->stream) == hipSuccess;
         ok = ok && run_frontend(e, APR_FLAVOUR_GO, e->d_pcm, span, (int)nw, stride, e->d_spec) == APR_OK;
         ok = ok && run_cnn(e, e->d_spec, (int)nw, trust, empty_class, nullptr, e->d_probs, e->d_label, e->d_match) == APR_OK;
-        ok = ok && hipMemcpyAsync(e->h_sg_probs, e->d_probs, nw * C * sizeof(double), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
-        ok = ok && hipMemcpyAsync(e->h_sg_label, e->d_label, nw * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
-        ok = ok && hipMemcpyAsync(e->h_sg_match, e->d_match, nw, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
-        hipGraph_t g = nullptr;
-        const bool ended = hipStreamEndCapture(e->stream, &g) == hipSuccess && g;
-        if (ok && ended && hipGraphInstantiate(&e->sg_exec, g, nullptr, nullptr, 0) != hipSuccess) e->sg_exec = nullptr;
-        if (g) (void)hipGraphDestroy(g);
-        if (!ok || !ended || !e->sg_exec) { e->sg_exec = nullptr; (void)hipGetLastError(); return kGraphUnavailable; }
-        e->sg_nw = nw; e->sg_span = span; e->sg_stride = stride; e->sg_trust = trust; e->sg_empty = empty_class;
-    }
-    if (span) memcpy(e->h_sg_pcm, pcm, span);
-    HIPCHK(e, hipGraphLaunch(e->sg_exec, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (probs) memcpy(probs, e->h_sg_probs, nw * C * sizeof(double));
-    if (label) memcpy(label, e->h_sg_label, nw * sizeof(int32_t));
-    if (match) memcpy(match, e->h_sg_match, nw);
+        ok = ok && hipMemcpyAsync(hp, e->d_probs, nw * C * sizeof(double), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(hl, e->d_label, nw * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        return ok && hipMemcpyAsync(hm, e->d_match, nw, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+    });
+    if (rc) return rc;
+    if (probs) memcpy(probs, hp, nw * C * sizeof(double));
+    if (label) memcpy(label, hl, nw * sizeof(int32_t));
+    if (match) memcpy(match, hm, nw);
+    return APR_OK;
+}
+
+// apr_infer as one graph launch
+int infer_graph(apr_engine *e, const float *spec, int nb, float *out_logits)
+{
+    int rc;
+    if ((rc = ensure_staging(e, 0)) || (rc = graph_staging(e))) return rc;
+    const size_t in_bytes = (size_t)nb * APR_SPEC_ELEMS * sizeof(float), out_bytes = (size_t)nb * e->n_classes * sizeof(float);
+    memcpy(e->h_g_in, spec, in_bytes);
+    rc = graph_replay(e, e->g_infer, (size_t)nb, 0, 0, 0.0, 0, [&]() {
+        bool ok = hipMemcpyAsync(e->d_spec, e->h_g_in, in_bytes, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && run_cnn(e, e->d_spec, nb, 0.0, -1, e->d_logits, nullptr, nullptr, nullptr) == APR_OK;
+        return ok && hipMemcpyAsync(e->h_g_out, e->d_logits, out_bytes, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+    });
+    if (rc) return rc;
+    memcpy(out_logits, e->h_g_out, out_bytes);
+    return APR_OK;
+}
+
+// apr_prepare_batch as one graph launch
+int prepare_graph(apr_engine *e, int flavour, const uint8_t *pcm, size_t span, size_t nw, size_t stride, float *out)
+{
+    int rc;
+    if ((rc = ensure_staging(e, span)) || (rc = graph_staging(e))) return rc;
+    const size_t out_bytes = nw * APR_SPEC_ELEMS * sizeof(float);
+    if (span) memcpy(e->h_g_in, pcm, span);
+    rc = graph_replay(e, e->g_prep[flavour], nw, span, stride, 0.0, 0, [&]() {
+        bool ok = true;
+        if (span) ok = hipMemcpyAsync(e->d_pcm, e->h_g_in, span, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && run_frontend(e, flavour, e->d_pcm, span, (int)nw, stride, e->d_spec) == APR_OK;
+        return ok && hipMemcpyAsync(e->h_g_out, e->d_spec, out_bytes, hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+    });
+    if (rc) return rc;
+    memcpy(out, e->h_g_out, out_bytes);
     return APR_OK;
 }
 
@@ -737,8 +797,8 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         rc = APR_ERR_DEVICE;
     }
     {
-        const char *genv = getenv("APR_GRAPH");   // APR_GRAPH=0: one-clip engines launch kernel by kernel
-        e->graph_on = e->max_batch <= 4 && !(genv && genv[0] == '0');
+        const char *genv = getenv("APR_GRAPH");   // APR_GRAPH=0: small calls launch kernel by kernel too
+        e->graph_on = !(genv && genv[0] == '0');
     }
     if (!rc) rc = build_frontend(e);
     if (!rc && has_model) rc = build_cnn(e, pm);
@@ -793,11 +853,10 @@ void apr_engine_destroy(apr_engine *e)
         if (e->ev_h2d[b]) (void)hipEventDestroy(e->ev_h2d[b]);
         if (e->ev_done[b]) (void)hipEventDestroy(e->ev_done[b]);
     }
-    if (e->sg_exec) (void)hipGraphExecDestroy(e->sg_exec);
-    if (e->h_sg_pcm) (void)hipHostFree(e->h_sg_pcm);
-    if (e->h_sg_probs) (void)hipHostFree(e->h_sg_probs);
-    if (e->h_sg_label) (void)hipHostFree(e->h_sg_label);
-    if (e->h_sg_match) (void)hipHostFree(e->h_sg_match);
+    for (GraphSlot *g : {&e->g_score, &e->g_infer, &e->g_prep[0], &e->g_prep[1]})
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (e->h_g_in) (void)hipHostFree(e->h_g_in);
+    if (e->h_g_out) (void)hipHostFree(e->h_g_out);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -845,6 +904,13 @@ int apr_prepare_batch(apr_engine *e, int flavour, const uint8_t *pcm, size_t tot
         return APR_ERR_INVALID;
     }
     int warn = 0;
+    if (graph_ok(e, n_windows, span_bytes(total_bytes, 0, n_windows, stride_bytes))) {
+        const size_t span = span_bytes(total_bytes, 0, n_windows, stride_bytes);
+        rc = prepare_graph(e, flavour, pcm, span, n_windows, stride_bytes, out);
+        if (rc == APR_OK) return span < (n_windows - 1) * stride_bytes + APR_SAMPLE_SIZE ? APR_WARN_UNDERFLOW : 0;
+        if (rc != kGraphUnavailable) return rc;
+        e->graph_on = false;
+    }
     for (size_t w0 = 0; w0 < n_windows; w0 += (size_t)e->max_batch) {
         const size_t nw = std::min<size_t>(e->max_batch, n_windows - w0);
         const size_t span = span_bytes(total_bytes, w0, nw, stride_bytes);
@@ -885,6 +951,11 @@ int apr_infer(apr_engine *e, const float *spec, int batch, float *out_logits)
     if (rc) return rc;
     if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
     if (batch < 0 || (batch && (!spec || !out_logits))) { e->err = "apr_infer: bad argument"; return APR_ERR_INVALID; }
+    if (graph_ok(e, (size_t)batch, (size_t)batch * APR_SPEC_ELEMS * sizeof(float))) {
+        rc = infer_graph(e, spec, batch, out_logits);
+        if (rc != kGraphUnavailable) return rc;
+        e->graph_on = false;
+    }
     if ((rc = ensure_staging(e, 0))) return rc;
     for (int b0 = 0; b0 < batch; b0 += e->max_batch) {
         const int nb = std::min(e->max_batch, batch - b0);
@@ -963,8 +1034,8 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
     if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
     if ((total_bytes && !pcm) || (n_windows > 1 && !stride_bytes)) { e->err = "apr_score: bad argument"; return APR_ERR_INVALID; }
     const int C = e->n_classes;
-    if (e->graph_on && !e->prof_on && n_windows >= 1 && n_windows <= (size_t)e->max_batch) {
-        rc = score_graph(e, pcm, total_bytes, n_windows, stride_bytes, trust, empty_class, probs, label, match);
+    if (graph_ok(e, n_windows, span_bytes(total_bytes, 0, n_windows, stride_bytes))) {
+        rc = score_graph(e, pcm, span_bytes(total_bytes, 0, n_windows, stride_bytes), n_windows, stride_bytes, trust, empty_class, probs, label, match);
         if (rc != kGraphUnavailable) return rc;   // capture not available: this engine launches kernel by kernel from now on
         e->graph_on = false;
     }

@@ -313,7 +313,7 @@ def softmax(logits) -> List[float]:
 
 def Infer(inferModel: OnnxModel, preparedAudio: np.ndarray) -> Dict[str, float]:
     """model.go:188-229: logits on the GPU, f64 softmax and label map on the host."""
-    e = engine_for(inferModel, 64)
+    e = engine_for(inferModel, 1)     # one clip per call, like the Go shim's Infer engine (split-K layers, graph replay)
     try:
         logits = e.infer_logits(np.asarray(preparedAudio, np.float32).reshape(1, Nmels, SpectrogramFrames))[0]
     except AprError as err:

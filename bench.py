@@ -202,9 +202,19 @@ def main() -> int:
             t1 = time.perf_counter()
             eng1.score(one, 1, trust=trust, empty_class=empty)
             lat.append(1e3 * (time.perf_counter() - t1))
-        eng1.close()
         out["p50_clip_latency_ms"] = float(np.median(lat[5:]))
         out["p99_clip_latency_ms"] = float(np.percentile(lat[5:], 99))
+        # the same clip through the reference API's two calls: Prepare (front-end handle), then Infer (model handle)
+        fe1 = model.Engine(None, local_rank, 64)
+        lat = []
+        for _ in range(40):
+            t1 = time.perf_counter()
+            spec, _w = fe1.prepare(one)
+            eng1.infer_logits(spec[None])
+            lat.append(1e3 * (time.perf_counter() - t1))
+        fe1.close()
+        eng1.close()
+        out["p50_prepare_plus_infer_ms"] = float(np.median(lat[5:]))
 
     # ---- CPU baseline: the oracle (port of the reference CPU path) on a bounded sample ----
     if args.cpu_windows > 0 and not args.no_extras and world == 1:   # rank 0 at N = 1 only

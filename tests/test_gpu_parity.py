@@ -327,6 +327,14 @@ def test_one_clip_graph_replay_equals_kernel_by_kernel(he_weights, monkeypatch):
         a = g.score(clip, 1, trust=trust, empty_class=empty)
         b = k.score(clip, 1, trust=trust, empty_class=empty)
         assert all(np.array_equal(a[key], b[key]) for key in ("probs", "label", "match")), (sec, nbytes)
+        # the reference API's two calls (Prepare, then Infer) replay graphs of their own
+        for flavour in (FLAVOUR_GO, FLAVOUR_LIBROSA):
+            sa, wa = g.prepare(clip, flavour)
+            sb, wb = k.prepare(clip, flavour)
+            assert wa == wb and np.array_equal(sa, sb), (sec, nbytes, flavour)
+        assert np.array_equal(g.infer_logits(sa[None]), k.infer_logits(sb[None]))
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    assert np.array_equal(g.infer_logits(specs), k.infer_logits(specs))      # six clips on a one-clip engine: six replays
     g.close(); k.close()
 
 
