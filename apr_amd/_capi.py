@@ -21,7 +21,7 @@ SYMBOLS = (
     "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable",
     "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
-    "apr_resample_taps", "apr_upsample", "apr_upsample_device",
+    "apr_resample_taps", "apr_upsample", "apr_upsample_device", "apr_stream_tick", "apr_stream_buffer", "apr_stream_reset",
 )
 
 
@@ -94,6 +94,12 @@ def lib():
     L.apr_upsample.restype = C.c_int
     L.apr_upsample_device.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp]
     L.apr_upsample_device.restype = C.c_int
+    L.apr_stream_tick.argtypes = [vp, u8p, C.c_int, C.c_double, C.c_int, f64p, vp, vp]
+    L.apr_stream_tick.restype = C.c_int
+    L.apr_stream_buffer.argtypes = [vp, C.c_int]
+    L.apr_stream_buffer.restype = C.c_void_p
+    L.apr_stream_reset.argtypes = [vp]
+    L.apr_stream_reset.restype = C.c_int
     L.apr_sync.argtypes = [vp]
     L.apr_sync.restype = C.c_int
     L.apr_engine_stream.argtypes = [vp]

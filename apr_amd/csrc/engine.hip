@@ -117,6 +117,11 @@ struct apr_engine {
     GraphSlot g_score, g_infer, g_prep[2];
     uint8_t *h_g_in = nullptr, *h_g_out = nullptr;   // kGraphIn / kGraphOut bytes, pinned
 
+    // apr_stream_tick: the previous 1-s segment of every live stream stays on the GPU
+    uint8_t *d_ring = nullptr;      // [ring_cap][APR_SAMPLE_SIZE]: previous || new
+    uint8_t *h_ring = nullptr;      // [ring_cap][APR_BYTES_PER_SECOND], pinned: the new segments of a tick
+    int ring_cap = 0, ring_n = 0;   // streams allocated / streams primed (0 = the next tick only primes)
+
     // profiling
     bool prof_on = false;
     apr_profile_slot slots[APR_PROF_SLOTS];
@@ -855,6 +860,7 @@ void apr_engine_destroy(apr_engine *e)
     }
     for (GraphSlot *g : {&e->g_score, &e->g_infer, &e->g_prep[0], &e->g_prep[1]})
         if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (e->h_ring) (void)hipHostFree(e->h_ring);
     if (e->h_g_in) (void)hipHostFree(e->h_g_in);
     if (e->h_g_out) (void)hipHostFree(e->h_g_out);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1054,6 +1060,72 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
     return APR_OK;
 }
 
+
+// ---- live mode: one new second per stream and tick (src/daemon/daemon.go:104-125) ----
+static int ring_reserve(apr_engine *e, int n_streams)
+{
+    if (n_streams <= e->ring_cap) return APR_OK;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->h_ring) { (void)hipHostFree(e->h_ring); e->h_ring = nullptr; }
+    e->ring_cap = 0;
+    e->ring_n = 0;
+    int rc;
+    if ((rc = dev_alloc(e, &e->d_ring, (size_t)n_streams * APR_SAMPLE_SIZE + 16))) return rc;   // an older ring stays in allocs until destroy
+    if (hipHostMalloc((void **)&e->h_ring, (size_t)n_streams * APR_BYTES_PER_SECOND, hipHostMallocDefault) != hipSuccess) {
+        e->h_ring = nullptr;
+        e->err = "apr_stream_tick: could not allocate pinned staging";
+        return APR_ERR_NOMEM;
+    }
+    e->ring_cap = n_streams;
+    return APR_OK;
+}
+
+uint8_t *apr_stream_buffer(apr_engine *e, int n_streams)
+{
+    if (check_engine(e)) return nullptr;
+    if (n_streams < 1 || n_streams > e->max_batch) { e->err = "apr_stream_buffer: n_streams must be 1 .. max_batch"; return nullptr; }
+    if (ring_reserve(e, n_streams)) return nullptr;
+    return e->h_ring;
+}
+
+int apr_stream_reset(apr_engine *e)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    e->ring_n = 0;
+    return APR_OK;
+}
+
+int apr_stream_tick(apr_engine *e, const uint8_t *segments, int n_streams, double trust, int empty_class, double *probs,
+                    int32_t *label, uint8_t *match)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if (!segments || n_streams < 1 || n_streams > e->max_batch) { e->err = "apr_stream_tick: bad argument (1 <= n_streams <= max_batch)"; return APR_ERR_INVALID; }
+    const bool own = e->h_ring && segments == e->h_ring && n_streams <= e->ring_cap;   // deposited in apr_stream_buffer's memory
+    if (!own && (rc = ring_reserve(e, n_streams))) return rc;
+    if ((rc = ensure_staging(e, 0))) return rc;
+    const size_t seg = APR_BYTES_PER_SECOND, win = APR_SAMPLE_SIZE;
+    const bool primed = e->ring_n == n_streams;
+    if (primed)   // previous <- new of the last tick (the halves of a row do not overlap)
+        HIPCHK(e, hipMemcpy2DAsync(e->d_ring, win, e->d_ring + seg, win, seg, (size_t)n_streams, hipMemcpyDeviceToDevice, e->stream));
+    if (!own) memcpy(e->h_ring, segments, (size_t)n_streams * seg);
+    HIPCHK(e, hipMemcpy2DAsync(e->d_ring + seg, win, e->h_ring, seg, seg, (size_t)n_streams, hipMemcpyHostToDevice, e->stream));
+    if (!primed) {   // the first segment of a stream has no predecessor: nothing to score yet (daemon.go:115-119)
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->ring_n = n_streams;
+        return APR_STREAM_PRIMED;
+    }
+    const int C = e->n_classes;
+    if ((rc = run_frontend(e, APR_FLAVOUR_GO, e->d_ring, (size_t)n_streams * win, n_streams, win, e->d_spec))) return rc;
+    if ((rc = run_cnn(e, e->d_spec, n_streams, trust, empty_class, nullptr, e->d_probs, e->d_label, e->d_match))) return rc;
+    if (probs) HIPCHK(e, hipMemcpyAsync(probs, e->d_probs, (size_t)n_streams * C * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    if (label) HIPCHK(e, hipMemcpyAsync(label, e->d_label, (size_t)n_streams * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    if (match) HIPCHK(e, hipMemcpyAsync(match, e->d_match, (size_t)n_streams, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return APR_OK;
+}
 
 // ---- integer-factor upsampler (resample.hip.h) ----
 static int upsample_check(apr_engine *e, size_t n_in, int up, const double *taps, int tpp, const void *in, const void *out)

@@ -181,6 +181,29 @@ class Engine:
                                       probs.ctypes.data, label.ctypes.data, match.ctypes.data))
         return dict(probs=probs, label=label, match=match)
 
+    def stream_buffer(self, n_streams: int) -> np.ndarray:
+        """apr_stream_buffer: the engine's pinned staging for one tick as a [n_streams, 96000] uint8 array."""
+        p = self._lib.apr_stream_buffer(self._h, n_streams)
+        if not p:
+            raise AprError(_capi.ERR_INVALID, (self._lib.apr_last_error(self._h) or b"").decode())
+        raw = (C.c_uint8 * (n_streams * BytesPerSecond)).from_address(p)
+        return np.frombuffer(raw, np.uint8).reshape(n_streams, BytesPerSecond)
+
+    def stream_reset(self) -> None:
+        self._chk(self._lib.apr_stream_reset(self._h))
+
+    def stream_tick(self, segments: np.ndarray, n_streams: int, trust: float = 0.5, empty_class: int = -1):
+        """apr_stream_tick: None while priming, else dict(probs, label, match) for the n_streams windows."""
+        seg = _as_u8(segments)
+        if seg.size != n_streams * BytesPerSecond:
+            raise ValueError("segments must hold n_streams x 96000 bytes")
+        probs = np.empty((n_streams, self.num_classes), np.float64)
+        label = np.empty(n_streams, np.int32)
+        match = np.empty(n_streams, np.uint8)
+        rc = self._chk(self._lib.apr_stream_tick(self._h, seg.ctypes.data, n_streams, trust, empty_class, probs.ctypes.data,
+                                                 label.ctypes.data, match.ctypes.data))
+        return None if rc == 1 else dict(probs=probs, label=label, match=match)
+
     def sweep_files(self, files, stride: int = BytesPerSecond, trust: float = 0.5, empty_class: int = -1):
         """apr_sweep_files over a list of host PCM buffers -> dict(probs, label, match, first_window [n_files+1])."""
         bufs = [_as_u8(f) for f in files]

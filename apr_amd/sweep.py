@@ -236,24 +236,23 @@ class MultiModelSweep:
 # (src/daemon/daemon.go:104-125: window = previous segment || new segment)
 # ----------------------------------------------------------------------------------------------
 class StreamScorer:
-    """Keeps the previous 1-s segment of every stream; ``tick(segments)`` scores the n_streams
-    windows [previous || new] in one GPU pass.  The first tick only primes the buffers
-    (daemon.go:115-119) and returns None."""
+    """Live mode (daemon.go:104-125) for n_streams streams over apr_stream_tick: the engine keeps every stream's
+    previous 1-s segment on the GPU; ``tick(segments)`` uploads the new ones and scores the n_streams windows
+    [previous || new] in one pass.  The first tick only primes the buffers (daemon.go:115-119) and returns None.
+    ``buffer`` is the engine's pinned staging as a [n_streams, 96000] uint8 array: a reader that deposits the
+    segments there and calls ``tick()`` without an argument skips the host copy."""
 
     def __init__(self, engine, n_streams: int, trust: float = 0.5, empty_class: int = -1):
         self.engine = engine
         self.n = n_streams
         self.trust = trust
         self.empty = empty_class
-        self.buf = np.zeros((n_streams, SAMPLE_SIZE), np.uint8)
-        self.primed = False
+        self.buffer = engine.stream_buffer(n_streams)
+        engine.stream_reset()
 
-    def tick(self, segments) -> Optional[dict]:
-        seg = np.ascontiguousarray(segments).view(np.uint8).reshape(self.n, BYTES_PER_SECOND)
-        if not self.primed:
-            self.buf[:, BYTES_PER_SECOND:] = seg
-            self.primed = True
-            return None
-        self.buf[:, :BYTES_PER_SECOND] = self.buf[:, BYTES_PER_SECOND:]
-        self.buf[:, BYTES_PER_SECOND:] = seg
-        return self.engine.score(self.buf, self.n, SAMPLE_SIZE, self.trust, self.empty)
+    def tick(self, segments=None) -> Optional[dict]:
+        if segments is None:
+            seg = self.buffer
+        else:
+            seg = np.ascontiguousarray(segments).view(np.uint8).reshape(self.n, BYTES_PER_SECOND)
+        return self.engine.stream_tick(seg, self.n, self.trust, self.empty)

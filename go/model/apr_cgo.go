@@ -48,6 +48,7 @@ var (
 	frontEnd *engine
 	engines  = map[uintptr]*engine{} // Infer: one clip per call
 	batchEngines = map[uintptr]*engine{} // ScoreBatch, SweepFiles
+	streamEngines = map[uintptr]*engine{} // StreamScorer (one engine per model; sized by the first NewStreamScorer)
 )
 
 func lastErr(h *C.apr_engine) string { return C.GoString(C.apr_last_error(h)) }
@@ -179,6 +180,69 @@ func ScoreBatch(inferModel OnnxModel, pcm []byte, trust float64) (probs [][]floa
 		match[k] = m[k] != 0
 	}
 	return
+}
+
+// StreamScorer is the live tick of daemon.go:104-125 for many streams at once (apr_stream_tick): the previous
+// 1-s segment of every stream stays on the GPU, a tick uploads the new ones and scores [previous || new] of all
+// streams in one pass.  Buffer() is the engine's pinned staging ([nStreams*BytesPerSecond]byte): a reader that
+// deposits the segments there and calls Tick(nil, ...) skips the host copy.
+type StreamScorer struct {
+	e *engine
+	n int
+	empty int
+	buf []byte
+}
+
+func NewStreamScorer(inferModel OnnxModel, nStreams int) *StreamScorer {
+	e := cachedEngine(inferModel, nStreams, streamEngines)
+	empty := -1
+	for i, l := range inferModel.Labels {
+		if l == "empty" {
+			empty = i
+		}
+	}
+	e.mu.Lock()
+	p := C.apr_stream_buffer(e.h, C.int(nStreams))
+	if p != nil {
+		C.apr_stream_reset(e.h)
+	}
+	e.mu.Unlock()
+	if p == nil {
+		log.Die("Inference failed: %v", lastErr(e.h))
+	}
+	return &StreamScorer{e: e, n: nStreams, empty: empty, buf: unsafe.Slice((*byte)(unsafe.Pointer(p)), nStreams*ffmpeg.BytesPerSecond)}
+}
+
+func (s *StreamScorer) Buffer() []byte { return s.buf }
+
+// Tick returns ok == false while the first segments only prime the buffers (daemon.go:115-119).
+func (s *StreamScorer) Tick(segments []byte, trust float64) (probs [][]float64, label []int32, match []bool, ok bool) {
+	if segments == nil {
+		segments = s.buf
+	}
+	if len(segments) != s.n*ffmpeg.BytesPerSecond {
+		log.Die("Inference failed: StreamScorer.Tick needs %d bytes", s.n*ffmpeg.BytesPerSecond)
+	}
+	flat := make([]float64, s.n*s.e.nc)
+	label = make([]int32, s.n)
+	m := make([]uint8, s.n)
+	s.e.mu.Lock()
+	rc := C.apr_stream_tick(s.e.h, (*C.uint8_t)(unsafe.Pointer(&segments[0])), C.int(s.n), C.double(trust), C.int(s.empty),
+		(*C.double)(unsafe.Pointer(&flat[0])), (*C.int32_t)(unsafe.Pointer(&label[0])), (*C.uint8_t)(unsafe.Pointer(&m[0])))
+	s.e.mu.Unlock()
+	if rc < 0 {
+		log.Die("Inference failed: %v", lastErr(s.e.h))
+	}
+	if rc == C.APR_STREAM_PRIMED {
+		return nil, nil, nil, false
+	}
+	probs = make([][]float64, s.n)
+	match = make([]bool, s.n)
+	for k := 0; k < s.n; k++ {
+		probs[k] = flat[k*s.e.nc : (k+1)*s.e.nc]
+		match[k] = m[k] != 0
+	}
+	return probs, label, match, true
 }
 
 // SweepFiles scores a list of decoded recordings in full GPU passes (short files share a pass, long

@@ -141,6 +141,27 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
               double trust, int empty_class, double *probs, int32_t *label, uint8_t *match);
 
 /*
+ * Live mode, the tick of src/daemon/daemon.go:104-125 for n_streams concurrent streams: every stream delivers one
+ * 1-s segment (APR_BYTES_PER_SECOND bytes) per tick and is scored on [its previous segment || the new one].  The
+ * engine keeps the previous segments on the GPU, so a tick uploads only the new second of every stream.
+ *   segments : [n_streams][APR_BYTES_PER_SECOND] bytes, host.  If it is the pointer apr_stream_buffer returned, the
+ *              segments are taken from there without a copy (the reader of the streams deposits them in that pinned
+ *              memory); any other host pointer is copied into it first.
+ * The first tick (after create, after apr_stream_reset, or when n_streams changes) has no previous segment: it only
+ * primes the buffers, writes no output and returns APR_STREAM_PRIMED, as the daemon drops a stream's first segment
+ * (daemon.go:115-119).  Later ticks return 0 and write probs/label/match as apr_score does ([n_streams] rows; any may be
+ * NULL).  1 <= n_streams <= max_batch.  Synchronous.
+ */
+#define APR_STREAM_PRIMED 1
+int apr_stream_tick(apr_engine *e, const uint8_t *segments, int n_streams, double trust, int empty_class, double *probs,
+                    int32_t *label, uint8_t *match);
+/* Pinned host memory for the segments of a tick ([n_streams][APR_BYTES_PER_SECOND]); owned by the engine, valid until a
+ * call with a larger n_streams or apr_engine_destroy.  NULL on error. */
+uint8_t *apr_stream_buffer(apr_engine *e, int n_streams);
+/* Forget the previous segments: the next tick primes again (the streams restarted; no counterpart in the reference, whose buffer lives in start_scanners, daemon.go:104-125). */
+int apr_stream_reset(apr_engine *e);
+
+/*
  * Same as apr_score with every buffer already resident in this engine's GPU
  * memory (hipMalloc'd / torch device tensors).  Asynchronous on the engine's
  * stream; call apr_sync before reading the outputs.  d_logits (optional)

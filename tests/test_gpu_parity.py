@@ -216,6 +216,16 @@ def test_stream_scorer_equals_batch_sweep(eng):
         for t in range(secs - 1):
             assert got[t]["label"][s] == ref["label"][t]
             assert np.array_equal(got[t]["probs"][s], ref["probs"][t])
+    # segments deposited in the engine's pinned staging (no host copy), after a restart of the streams
+    sc2 = sweep.StreamScorer(eng, n_streams, trust=0.5, empty_class=2)
+    for t in range(secs):
+        sc2.buffer[:] = np.stack([p[t] for p in pcm])
+        r = sc2.tick()
+        assert (r is None) == (t == 0)
+        if t:
+            assert all(np.array_equal(r[k], got[t - 1][k]) for k in ("probs", "label", "match"))
+    with pytest.raises(AprError):
+        eng.stream_buffer(65)            # more streams than max_batch
 
 
 def test_dat_clip_round_trip_and_librosa_batch(fe, clips, tmp_path):
