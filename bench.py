@@ -26,6 +26,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_F32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 (vector), packed FMA
+PEAK_HBM_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E
 LABELS = ["big_dog", "combination", "empty", "small_dog"]   # src/model/test_model.labels:1
 
 
@@ -177,11 +179,21 @@ def main() -> int:
                            "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
                            "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
                            "share_of_gpu_time": dom["ms"] / tot_ms}
-        out["kernels"] = [
-            {"name": k, "ms_per_step": v["ms"] / args.steps, "launches": v["launches"],
-             "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None,
-             "alg_GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
-            for k, v in fam.items()]
+        def stage(k, v):
+            tf = (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None
+            gb = (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None
+            # the roof each stage is priced against: matrix cores for the convolutions, fp32 VALU issue
+            # for the STFT/mel kernel (its HBM fraction is reported beside it), HBM for the elementwise kernels
+            if "igemm" in k or "wino_fused" in k or "conv12" in k:
+                bound, frac = "mfma", tf / PEAK_F32_MFMA_TFLOPS if tf else None
+            elif "stft" in k:
+                bound, frac = "valu", tf / PEAK_F32_VALU_TFLOPS if tf else None
+            else:
+                bound, frac = "hbm", gb / PEAK_HBM_GBPS if gb else None
+            return {"name": k, "ms_per_step": v["ms"] / args.steps, "launches": v["launches"], "tflops": tf, "alg_GBps": gb,
+                    "bound": bound, "frac": frac, "hbm_frac": gb / PEAK_HBM_GBPS if gb else None,
+                    "share_of_gpu_time": v["ms"] / tot_ms}
+        out["kernels"] = [stage(k, v) for k, v in fam.items()]
         out["layers"] = [{"layer": s["layer"], "kernel": s["name"], "ms_per_step": s["ms"] / args.steps,
                           "tflops": (s["flops"] / (s["ms"] * 1e-3) / 1e12) if s["ms"] > 0 else None}
                          for s in prof if s["layer"] > 0]
