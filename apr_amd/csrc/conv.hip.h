@@ -129,6 +129,12 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rs, unsigned voff, int soff, 
 //   single clip: layer 12 has 8 tiles of 576 K steps): blockIdx.y = split s takes K steps
 //   [KT s / S, KT (s+1) / S) and stores its raw partial sums to out[s][M][Cout];
 //   splitk_reduce_kernel adds them in split order (deterministic) with bias + ReLU.
+//   MODE 3 is the stride-2 convolution in its polyphase Winograd F(2,2) form (wino_s2.hip.h): 25 GEMMs
+//   [T tiles x Cin] x [Cin x Cout], blockIdx.y = position p = 5 pr + pc, whose A operand is the input transform
+//   B^T d B of the tile's 5x5 patch, formed in this kernel's loader: at most two patch rows times two patch
+//   columns, signs +-1 (block-uniform), out-of-image pixels read as 0.  H, W = the input image, Ho, Wo = the tile
+//   grid (th, tw), M = T.  wt = the 16 distinct weight matrices U[4 min(pr,3) + min(pc,3)][Cin][Cout]; raw stores
+//   to out[p][T][Cout] (wino_s2_output does A^T m A + bias + ReLU).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int STRIDE, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restrict__ in,
@@ -172,9 +178,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     //      load instead of 64-bit pointer arithmetic.  Zero padding and rows past M use an
     //      out-of-range offset: the buffer unit returns 0 for those lanes.
     constexpr unsigned OOB = 0x80000000u;            // >= num_records of the A descriptor
-    constexpr int TAPS = MODE != 1 ? 9 : 1;
-    const int p0 = bm * BM;                          // first output pixel of this block (< M)
+    constexpr int TAPS = (MODE == 1 || MODE == 3) ? 1 : 9;
+    const int p0 = bm * BM;                          // first output pixel (MODE 3: tile) of this block (< M)
     const long long b0 = MODE != 1 ? (p0 / Wo) / Ho : 0;   // its window
+    // MODE 3: the terms of this block's position.  Row transform B^T = [d0 - d2, d2, d4 - d2, d1, d3]: first patch row
+    // (always), second patch row (-1: none; it enters with a minus sign); the same for columns.
+    int s3r0 = 0, s3r1 = -1, s3c0 = 0, s3c1 = -1;
+    if (MODE == 3) {
+        const int pr = (int)blockIdx.y / 5, pc = (int)blockIdx.y - 5 * pr;
+        s3r0 = pr == 0 ? 0 : pr == 1 ? 2 : pr == 2 ? 4 : pr == 3 ? 1 : 3;
+        s3r1 = (pr == 0 || pr == 2) ? 2 : -1;
+        s3c0 = pc == 0 ? 0 : pc == 1 ? 2 : pc == 2 ? 4 : pc == 3 ? 1 : 3;
+        s3c1 = (pc == 0 || pc == 2) ? 2 : -1;
+        wt += (size_t)(4 * (pr < 3 ? pr : 3) + (pc < 3 ? pc : 3)) * Cin * Cout;
+        out += (size_t)blockIdx.y * M * Cout;
+    }
     if (MODE == 1) {                                 // batched GEMM: this block's problem
         in += (size_t)blockIdx.y * M * Cin;
         wt += (size_t)blockIdx.y * Cin * Cout;
@@ -197,6 +215,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         rowoff[i] = OOB;
         if (MODE == 1) {
             if (p < M) { rowoff[i] = 4u * (unsigned)((ar0 + AR * i) * Cin + ac * 4); rowmask[i] = 1u; }
+        } else if (MODE == 3) {
+            if (p < M) {   // tile p = (window, ty, tx): patch rows 4 ty - 1 .. 4 ty + 3, columns 4 tx - 1 .. 4 tx + 3
+                const int tx = p % Wo;
+                const int t = p / Wo;
+                const int ty = t % Ho;
+                const int db = t / Ho - (int)b0;
+                rowoff[i] = 4u * (unsigned)(((db * H + 4 * ty) * W + 4 * tx) * Cin + ac * 4);   // from abase (one row, one column early)
+                unsigned rok = 0, cok = 0;
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    const int ih = 4 * ty - 1 + j, iw = 4 * tx - 1 + j;
+                    if (ih >= 0 && ih < H) rok |= 1u << j;
+                    if (iw >= 0 && iw < W) cok |= 1u << j;
+                }
+                rowmask[i] = rok | (cok << 8);
+            }
         } else if (p < M) {
             const int ow = p % Wo;
             const int t = p / Wo;
@@ -238,12 +272,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const int kt1 = (int)(((long long)KT * (ks + 1)) / kn);
 
     f32x4 ra[AROWS], rb[BPASS];
+    f32x4 ra3[MODE == 3 ? 3 : 1][AROWS];   // MODE 3: the other three terms of the A operand
     // K order for Cin >= 128: (tap row dy, channel chunk, tap column dx).  The three dx taps of one 64-B
     // channel chunk touch the same input lines shifted by a pixel; run back to back they hit in cache
     // instead of coming round again Cin/16 K steps later (measured HBM fetch of the stride-2 layers 4..8:
     // -17 %).  Narrow layers (Cin = 32: one pixel = one 128-B line = two chunks) keep tap-major order,
     // which reads both halves of a line in consecutive K steps (the other order fetched 30 % more).
-    const bool dx_inner = MODE != 1 && cchunks >= 8;
+    const bool dx_inner = MODE != 1 && MODE != 3 && cchunks >= 8;
 #define APR_KT_SPLIT(KT_)                                                                                \
         int tap_, c0_;                                                                                   \
         if (dx_inner) {                                                                                  \
@@ -261,10 +296,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         APR_KT_SPLIT(KT_)                                                                                \
         const int soffA_ = MODE != 1 ? 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_) : 4 * c0_;        \
         const int soffB_ = 4 * (tap_ * Cin + c0_) * Cout;                                                \
+        if (MODE == 3) {                                                                                 \
+            /* term (r, c): patch pixel (s3r, s3c); absent terms and out-of-image pixels read as 0 (out-of-range offset) */ \
+            _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                            \
+            {                                                                                            \
+                const unsigned rk_ = rowmask[i] & 0xFFu, ck_ = rowmask[i] >> 8;                          \
+                const bool r0_ = (rk_ >> s3r0) & 1u, r1_ = s3r1 >= 0 && ((rk_ >> (s3r1 & 7)) & 1u);      \
+                const bool c0k_ = (ck_ >> s3c0) & 1u, c1k_ = s3c1 >= 0 && ((ck_ >> (s3c1 & 7)) & 1u);    \
+                const int o00_ = 4 * ((s3r0 * W + s3c0) * Cin + c0_), o01_ = 4 * ((s3r0 * W + (s3c1 & 7)) * Cin + c0_); \
+                const int o10_ = 4 * (((s3r1 & 7) * W + s3c0) * Cin + c0_), o11_ = 4 * (((s3r1 & 7) * W + (s3c1 & 7)) * Cin + c0_); \
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r0_ && c0k_ ? rowoff[i] : OOB, o00_, 0)); \
+                /* the position's absent terms are skipped by block-uniform branches: 49 loads per 25 positions, not 100 */ \
+                if (s3c1 >= 0) ra3[0][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r0_ && c1k_ ? rowoff[i] : OOB, o01_, 0)); \
+                if (s3r1 >= 0) ra3[1][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r1_ && c0k_ ? rowoff[i] : OOB, o10_, 0)); \
+                if (s3r1 >= 0 && s3c1 >= 0) ra3[2][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r1_ && c1k_ ? rowoff[i] : OOB, o11_, 0)); \
+            }                                                                                            \
+        } else {                                                                                         \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
             const unsigned vo_ = ((rowmask[i] >> tap_) & 1u) ? rowoff[i] : OOB;                          \
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, vo_, soffA_, 0)); \
+        }                                                                                                \
         }                                                                                                \
         if (!APR_EXP_BDMA) {                                                                             \
             _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                            \
@@ -284,6 +336,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #define APR_STORE_A(BUF_, I_)                                                                            \
     {                                                                                                    \
         float *a_ = As[BUF_] + ar0 + AR * (I_);                                                          \
+        if (MODE == 3) {   /* (d[r0][c0] - d[r0][c1]) - (d[r1][c0] - d[r1][c1]), absent terms left out */ \
+            if (s3c1 >= 0) ra[I_] -= ra3[0][I_];                                                         \
+            if (s3r1 >= 0) {                                                                             \
+                f32x4 t_ = ra3[1][I_];                                                                   \
+                if (s3c1 >= 0) t_ -= ra3[2][I_];                                                         \
+                ra[I_] -= t_;                                                                            \
+            }                                                                                            \
+        }                                                                                                \
         a_[(ac * 4 + 0) * LDA] = ra[I_].x;                                                               \
         a_[(ac * 4 + 1) * LDA] = ra[I_].y;                                                               \
         a_[(ac * 4 + 2) * LDA] = ra[I_].z;                                                               \
@@ -361,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = bn * BN + wn * WN + j * 32 + li;
-        const float bv = MODE == 0 ? bias[n] : 0.0f;
+        const float bv = MODE == 0 ? bias[n] : 0.0f;   // (MODE 1, 2, 3: raw sums)
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int prow = p0 + wm * WM + i * 32 + 4 * half;

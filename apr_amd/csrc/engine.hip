@@ -22,6 +22,7 @@
 #include "conv12_fused.hip.h"
 #include "wino_fused.hip.h"
 #include "wino_fused8.hip.h"
+#include "wino_s2.hip.h"
 
 using namespace apr;
 
@@ -35,7 +36,8 @@ struct Layer {
     float *d_b = nullptr;   // [cout]
     int bn_tile = 0, bm_tile = 128;
     // Winograd F(2x2,3x3) path (stride-1 layers with enough channels to amortise the transforms)
-    int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2)
+    int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2),
+                            // 4 = stride 2 in polyphase Winograd F(2,2) form (wino_s2.hip.h: 25 GEMMs + output transform)
     int fused_waves = 8;    // wino == 3: wino_fused8_f2 (8 waves a block) or wino_fused_f2 (4)
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
     int th = 0, tw = 0;     // 2x2-output tiles per window
@@ -297,6 +299,14 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     // 2048 windows: 58.0 vs 67.6 ms and 29.0 vs 31.9 ms a step); small engines keep transform kernels + batched GEMM there
     // one-clip engines (max_batch <= 4): 24 or 16 work units of layers 5 and 7 leave the chip idle while each walks 16 or 32 K
     // steps (39.8 and 71.5 us); transform kernels + 16 batched GEMMs spread the same work over 100+ workgroups (25.6 and 31.8 us)
+    // Stride-2 layers in polyphase Winograd F(2,2) form (wino_s2.hip.h): 25/36 of the products, against a round trip of
+    // M[25][T][Cout] through HBM -- pays where Cin is large and a pass is big enough to fill the 25 GEMM grids.
+    // APR_WINO_S2=0 turns it off; APR_WINO_S2_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests).
+    const char *s2env = getenv("APR_WINO_S2");
+    const bool wino_s2_on = wino_on && !(s2env && s2env[0] == '0');
+    const int wino_s2_min_cin = getenv("APR_WINO_S2_MIN_CIN") ? atoi(getenv("APR_WINO_S2_MIN_CIN")) : 512;
+    const int wino_s2_min_px = getenv("APR_WINO_S2_MIN_PX") ? atoi(getenv("APR_WINO_S2_MIN_PX")) : 24;
+    const int wino_s2_min_batch = getenv("APR_WINO_S2_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_MIN_BATCH")) : 1024;
     const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
@@ -377,6 +387,19 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             v_max = std::max(v_max, (size_t)16 * L.th * L.tw * cv.cin);
             m_max = std::max(m_max, (size_t)L.wsplit * 16 * L.th * L.tw * cv.cout);
         }
+        if (!L.wino && wino_s2_on && l > 0 && cv.stride == 2 && cv.cin >= wino_s2_min_cin && cv.cin % 16 == 0 && cv.cout % 128 == 0 &&
+            L.hout * L.wout >= wino_s2_min_px && e->max_batch >= wino_s2_min_batch) {
+            std::vector<float> u((size_t)16 * cv.cin * cv.cout);
+            wino_s2_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
+            if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+            L.wino = 4;
+            L.ksplit = 1;
+            L.th = (L.hout + 1) / 2;
+            L.tw = (L.wout + 1) / 2;
+            const long long t_full = (long long)e->max_batch * L.th * L.tw;
+            L.wbm_tile = ((t_full + 127) / 128) * (cv.cout / 128) * 25 < 1024 ? 64 : 128;
+            m_max = std::max(m_max, (size_t)25 * L.th * L.tw * cv.cout);
+        }
         act_max = std::max(act_max, (size_t)L.cout * L.hout * L.wout);
         h = L.hout; w = L.wout;
         e->layers.push_back(L);
@@ -398,7 +421,8 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     for (int i = 0; i < 2; i++)
         if ((rc = dev_alloc(e, &e->d_act[i], act_max * (size_t)e->max_batch))) return rc;
     if (part_max && (rc = dev_alloc(e, &e->d_part, part_max))) return rc;
-    if (v_max && ((rc = dev_alloc(e, &e->d_V, v_max * (size_t)e->max_batch)) || (rc = dev_alloc(e, &e->d_M, m_max * (size_t)e->max_batch)))) return rc;
+    if (v_max && (rc = dev_alloc(e, &e->d_V, v_max * (size_t)e->max_batch))) return rc;
+    if (m_max && (rc = dev_alloc(e, &e->d_M, m_max * (size_t)e->max_batch))) return rc;
     return APR_OK;
 }
 
@@ -531,6 +555,28 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             else
                 hipLaunchKernelGGL(wino_fused8_f2, dim3(wf8_grid((int)(tiles_m * tiles_n), e->n_cus)), dim3(512), WF8_LDS_BYTES, e->stream, in, L.d_u,
                                    L.d_b, out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw), (int)(tiles_m * tiles_n));
+            in = out;
+            continue;
+        }
+        if (L.wino == 4) {
+            const long long T = (long long)batch * L.th * L.tw;
+            const long long nm = T * (L.cout / 4);
+            {
+                ProfScope ps(e, L.slot, 2.0 * 25.0 * (double)T * L.cin * L.cout,
+                             4.0 * ((double)batch * L.hin * L.win * L.cin + 25.0 * (double)T * L.cout + 16.0 * L.cin * L.cout));
+                const int tiles_n = L.cout / 128;
+                if (L.wbm_tile == 64)
+                    hipLaunchKernelGGL((conv3x3_igemm_f32<64, 128, 1, 3>), dim3((unsigned)(((T + 63) / 64) * tiles_n), 25), dim3(256), 0, e->stream, in,
+                                       L.d_u, L.d_b, e->d_M, L.hin, L.win, L.cin, L.th, L.tw, L.cout, (int)T, tiles_n);
+                else
+                    hipLaunchKernelGGL((conv3x3_igemm_f32<128, 128, 1, 3>), dim3((unsigned)(((T + 127) / 128) * tiles_n), 25), dim3(256), 0, e->stream, in,
+                                       L.d_u, L.d_b, e->d_M, L.hin, L.win, L.cin, L.th, L.tw, L.cout, (int)T, tiles_n);
+            }
+            {
+                ProfScope ps(e, L.slot_out, 0.0, 4.0 * (25.0 * T * L.cout + (double)M * L.cout));
+                hipLaunchKernelGGL(wino_s2_output, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
+                                   e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
+            }
             in = out;
             continue;
         }
@@ -814,6 +860,7 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
             if (e->fuse12 && l == 0) continue;   // no kernel of its own
             if (e->fuse12 && l == 1) snprintf(nm, sizeof nm, "conv12_fused_kernel");
             else if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
+            else if (L.wino == 4) snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 3>", L.wbm_tile);
             else if (L.wino) {
                 L.slot_in = e->n_slots;
                 add_slot(e, "wino_input_f2", (int)l + 1);
@@ -825,6 +872,9 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
             if (L.wino == 2) {
                 L.slot_out = e->n_slots;
                 add_slot(e, "wino_output_f2", (int)l + 1);
+            } else if (L.wino == 4) {
+                L.slot_out = e->n_slots;
+                add_slot(e, "wino_s2_output", (int)l + 1);
             } else if (L.ksplit > 1) {
                 L.slot_out = e->n_slots;
                 add_slot(e, "splitk_reduce_kernel", (int)l + 1);

@@ -280,6 +280,33 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
     assert np.array_equal(fused, fused1)                # batch size / chunking is bit-invisible
 
 
+def test_stride2_polyphase_winograd_layers(he_weights, monkeypatch):
+    # The stride-2 layers in polyphase Winograd F(2,2) form (wino_s2.hip.h; engines of max_batch >= 1024 use it on layers
+    # 6, 8, 10).  Forced here on every stride-2 layer from 4 on in a small engine: odd widths (47 -> 24 tiles of 2), the
+    # 2x3 image of layer 12, ragged last blocks; against the reference's logits and the direct kernels.
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
+    blob = W.pack_blob(he_weights, 4)
+
+    def run(env, batch):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = model.Engine(blob, 0, batch)
+        for k in env:
+            monkeypatch.delenv(k)
+        out = e.infer_logits(specs)
+        e.close()
+        return out
+
+    force = {"APR_WINO_S2_MIN_BATCH": "1", "APR_WINO_S2_MIN_CIN": "128", "APR_WINO_S2_MIN_PX": "1"}
+    base = run({"APR_WINO_S2": "0"}, 8)
+    s2 = run(force, 8)
+    s2b = run(force, 5)                                # six clips in chunks of 5 and 1
+    assert np.abs(s2 - want).max() <= LOGIT_TOL
+    assert np.abs(s2 - base).max() <= 2e-5 and not np.array_equal(s2, base)
+    assert np.array_equal(s2, s2b)
+
+
 def test_sweep_files_equals_per_file_score(he_weights):
     # ragged list: packed into shared passes, split across passes, empty and too-short files, short tail windows
     eng = model.Engine(W.pack_blob(he_weights, 4), 0, 16)
