@@ -304,9 +304,13 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     // APR_WINO_S2=0 turns it off; APR_WINO_S2_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests).
     const char *s2env = getenv("APR_WINO_S2");
     const bool wino_s2_on = wino_on && !(s2env && s2env[0] == '0');
-    const int wino_s2_min_cin = getenv("APR_WINO_S2_MIN_CIN") ? atoi(getenv("APR_WINO_S2_MIN_CIN")) : 512;
-    const int wino_s2_min_px = getenv("APR_WINO_S2_MIN_PX") ? atoi(getenv("APR_WINO_S2_MIN_PX")) : 24;
-    const int wino_s2_min_batch = getenv("APR_WINO_S2_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_MIN_BATCH")) : 1024;
+    // Passes of >= 1024 windows: layers 8 and 10 (Cin 512, >= 24 pixels a window; measured 100.6 vs 115.5 and 25.3 vs 29.4 ms a
+    // step; layer 6 loses 4 ms, layer 12 pads 2x3 pixels to 2x4).  Passes of 128..1023 windows (live mode): layers 6 to 12 --
+    // there the direct kernel's grids are short (layer 12 at 256 windows: 192 workgroups of 576 K steps, 620 us against 260).
+    const bool s2_big = e->max_batch >= 1024;
+    const int wino_s2_min_cin = getenv("APR_WINO_S2_MIN_CIN") ? atoi(getenv("APR_WINO_S2_MIN_CIN")) : (s2_big ? 512 : 256);
+    const int wino_s2_min_px = getenv("APR_WINO_S2_MIN_PX") ? atoi(getenv("APR_WINO_S2_MIN_PX")) : (s2_big ? 24 : 1);
+    const int wino_s2_min_batch = getenv("APR_WINO_S2_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_MIN_BATCH")) : 128;
     const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
