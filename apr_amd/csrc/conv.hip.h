@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const int kt1 = (int)(((long long)KT * (ks + 1)) / kn);
 
     f32x4 ra[AROWS], rb[BPASS];
-    f32x4 ra3[MODE == 3 ? 3 : 1][AROWS];   // MODE 3: the other three terms of the A operand
+    f32x4 ra3[3];   // MODE 3: the other three terms of ONE A row (the rows of a thread are loaded and stored one after the other,
+                    // so that a single set of temporaries keeps the kernel at 4 workgroups per CU)
     // K order for Cin >= 128: (tap row dy, channel chunk, tap column dx).  The three dx taps of one 64-B
     // channel chunk touch the same input lines shifted by a pixel; run back to back they hit in cache
     // instead of coming round again Cin/16 K steps later (measured HBM fetch of the stride-2 layers 4..8:
@@ -296,21 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         APR_KT_SPLIT(KT_)                                                                                \
         const int soffA_ = MODE != 1 ? 4 * (((tap_ / 3) * W + (tap_ % 3)) * Cin + c0_) : 4 * c0_;        \
         const int soffB_ = 4 * (tap_ * Cin + c0_) * Cout;                                                \
-        if (MODE == 3) {                                                                                 \
-            /* term (r, c): patch pixel (s3r, s3c); absent terms and out-of-image pixels read as 0 (out-of-range offset) */ \
-            _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                            \
-            {                                                                                            \
-                const unsigned rk_ = rowmask[i] & 0xFFu, ck_ = rowmask[i] >> 8;                          \
-                const bool r0_ = (rk_ >> s3r0) & 1u, r1_ = s3r1 >= 0 && ((rk_ >> (s3r1 & 7)) & 1u);      \
-                const bool c0k_ = (ck_ >> s3c0) & 1u, c1k_ = s3c1 >= 0 && ((ck_ >> (s3c1 & 7)) & 1u);    \
-                const int o00_ = 4 * ((s3r0 * W + s3c0) * Cin + c0_), o01_ = 4 * ((s3r0 * W + (s3c1 & 7)) * Cin + c0_); \
-                const int o10_ = 4 * (((s3r1 & 7) * W + s3c0) * Cin + c0_), o11_ = 4 * (((s3r1 & 7) * W + (s3c1 & 7)) * Cin + c0_); \
-                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r0_ && c0k_ ? rowoff[i] : OOB, o00_, 0)); \
-                /* the position's absent terms are skipped by block-uniform branches: 49 loads per 25 positions, not 100 */ \
-                if (s3c1 >= 0) ra3[0][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r0_ && c1k_ ? rowoff[i] : OOB, o01_, 0)); \
-                if (s3r1 >= 0) ra3[1][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r1_ && c0k_ ? rowoff[i] : OOB, o10_, 0)); \
-                if (s3r1 >= 0 && s3c1 >= 0) ra3[2][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r1_ && c1k_ ? rowoff[i] : OOB, o11_, 0)); \
-            }                                                                                            \
+        if (MODE == 3) {   /* A rows: APR_LOAD_A3, one row at a time */                                  \
         } else {                                                                                         \
         _Pragma("unroll") for (int i = 0; i < AROWS; i++)                                                \
         {                                                                                                \
@@ -322,6 +309,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
             _Pragma("unroll") for (int i = 0; i < BPASS; i++)                                            \
                 rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, boff[i], soffB_, 0)); \
         }                                                                                                \
+    }
+    // MODE 3: the terms of A row I_.  Term (r, c) = patch pixel (s3r, s3c); out-of-image pixels read as 0 (out-of-range offset);
+    // the position's absent terms are skipped by block-uniform branches: 49 loads per 25 positions, not 100.
+#define APR_LOAD_A3(KT_, I_)                                                                             \
+    {                                                                                                    \
+        const int c0_ = (KT_) * BK;                                                                      \
+        const unsigned rk_ = rowmask[I_] & 0xFFu, ck_ = rowmask[I_] >> 8;                                \
+        const bool r0_ = (rk_ >> s3r0) & 1u, r1_ = s3r1 >= 0 && ((rk_ >> (s3r1 & 7)) & 1u);              \
+        const bool c0k_ = (ck_ >> s3c0) & 1u, c1k_ = s3c1 >= 0 && ((ck_ >> (s3c1 & 7)) & 1u);            \
+        const int o00_ = 4 * ((s3r0 * W + s3c0) * Cin + c0_), o01_ = 4 * ((s3r0 * W + (s3c1 & 7)) * Cin + c0_); \
+        const int o10_ = 4 * (((s3r1 & 7) * W + s3c0) * Cin + c0_), o11_ = 4 * (((s3r1 & 7) * W + (s3c1 & 7)) * Cin + c0_); \
+        ra[I_] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r0_ && c0k_ ? rowoff[I_] : OOB, o00_, 0)); \
+        if (s3c1 >= 0) ra3[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r0_ && c1k_ ? rowoff[I_] : OOB, o01_, 0)); \
+        if (s3r1 >= 0) ra3[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r1_ && c0k_ ? rowoff[I_] : OOB, o10_, 0)); \
+        if (s3r1 >= 0 && s3c1 >= 0) ra3[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, r1_ && c1k_ ? rowoff[I_] : OOB, o11_, 0)); \
     }
     // B tile straight into LDS (LDS-DMA, no VGPRs, no ds_write): one wave-instruction writes
     // 1 KiB = 64 lanes x 16 B contiguously, which is exactly (64/BCH) whole k-rows of Bs.
@@ -337,10 +339,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     {                                                                                                    \
         float *a_ = As[BUF_] + ar0 + AR * (I_);                                                          \
         if (MODE == 3) {   /* (d[r0][c0] - d[r0][c1]) - (d[r1][c0] - d[r1][c1]), absent terms left out */ \
-            if (s3c1 >= 0) ra[I_] -= ra3[0][I_];                                                         \
+            if (s3c1 >= 0) ra[I_] -= ra3[0];                                                             \
             if (s3r1 >= 0) {                                                                             \
-                f32x4 t_ = ra3[1][I_];                                                                   \
-                if (s3c1 >= 0) t_ -= ra3[2][I_];                                                         \
+                f32x4 t_ = ra3[1];                                                                       \
+                if (s3c1 >= 0) t_ -= ra3[2];                                                             \
                 ra[I_] -= t_;                                                                            \
             }                                                                                            \
         }                                                                                                \
@@ -361,8 +363,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 
     APR_LOAD_TILES(kt0)
     if (APR_EXP_BDMA) APR_DMA_B(kt0, 0)
+    if (MODE == 3) {
 #pragma unroll
-    for (int i = 0; i < AROWS; i++) APR_STORE_A(0, i)
+        for (int i = 0; i < AROWS; i++) { APR_LOAD_A3(kt0, i) APR_STORE_A(0, i) }
+    } else {
+#pragma unroll
+        for (int i = 0; i < AROWS; i++) APR_STORE_A(0, i)
+    }
     if (!APR_EXP_BDMA) {
 #pragma unroll
         for (int i = 0; i < BPASS; i++) APR_STORE_B(0, i)
@@ -393,7 +400,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
             __builtin_amdgcn_sched_barrier(0x6);                                                         \
             if (APR_EXP_STAGE && APR_EXP_LOAD && HAS_NEXT && kk == 1) APR_LOAD_TILES(kt + 1)             \
             if (APR_EXP_STAGE && APR_EXP_BDMA && HAS_NEXT && kk == 2) APR_DMA_B(kt + 1, cur ^ 1)         \
-            if (APR_EXP_STAGE && APR_EXP_STORE && HAS_NEXT && kk >= ST0 && kk < ST0 + AROWS) APR_STORE_A(cur ^ 1, kk - ST0) \
+            if (MODE != 3 && APR_EXP_STAGE && APR_EXP_STORE && HAS_NEXT && kk >= ST0 && kk < ST0 + AROWS) APR_STORE_A(cur ^ 1, kk - ST0) \
+            if (MODE == 3 && HAS_NEXT) {   /* row 0: loaded after k-pair 0, stored at 3; row 1: loaded at 3, stored at 6 */ \
+                constexpr int R1 = AROWS > 1 ? 1 : 0;                                                    \
+                if (kk == 0) APR_LOAD_A3(kt + 1, 0)                                                      \
+                if (kk == 3) { APR_STORE_A(cur ^ 1, 0) if (AROWS > 1) APR_LOAD_A3(kt + 1, R1) }          \
+                if (AROWS > 1 && kk == 6) APR_STORE_A(cur ^ 1, R1)                                       \
+            }                                                                                            \
             if (APR_EXP_STAGE && APR_EXP_STORE && !APR_EXP_BDMA && HAS_NEXT && kk >= ST0 && kk < ST0 + BPASS) APR_STORE_B(cur ^ 1, kk - ST0) \
             if (APR_EXP_STAGE && !APR_EXP_STORE && HAS_NEXT && kk == ST0) {                              \
                 _Pragma("unroll") for (int i = 0; i < AROWS; i++) asm volatile("" ::"v"(ra[i]));          \
@@ -445,6 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 }
 
 #undef APR_LOAD_TILES
+#undef APR_LOAD_A3
 #undef APR_KT_SPLIT
 #undef APR_STORE_A
 #undef APR_STORE_B
