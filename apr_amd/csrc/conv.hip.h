@@ -129,12 +129,15 @@ __device__ __forceinline__ void lds_dma_b128(i32x4 rs, unsigned voff, int soff, 
 //   single clip: layer 12 has 8 tiles of 576 K steps): blockIdx.y = split s takes K steps
 //   [KT s / S, KT (s+1) / S) and stores its raw partial sums to out[s][M][Cout];
 //   splitk_reduce_kernel adds them in split order (deterministic) with bias + ReLU.
-//   MODE 3 is the stride-2 convolution in its polyphase Winograd F(2,2) form (wino_s2.hip.h): 25 GEMMs
-//   [T tiles x Cin] x [Cin x Cout], blockIdx.y = position p = 5 pr + pc, whose A operand is the input transform
+//   MODE 3 is the stride-2 convolution in its polyphase Winograd F(2,2) form (wino_s2.hip.h): 25 products
+//   [T tiles x Cin] x [Cin x Cout], one per position p = (pr, pc), whose A operand is the input transform
 //   B^T d B of the tile's 5x5 patch, formed in this kernel's loader: at most two patch rows times two patch
-//   columns, signs +-1 (block-uniform), out-of-image pixels read as 0.  H, W = the input image, Ho, Wo = the tile
-//   grid (th, tw), M = T.  wt = the 16 distinct weight matrices U[4 min(pr,3) + min(pc,3)][Cin][Cout]; raw stores
-//   to out[p][T][Cout] (wino_s2_output does A^T m A + bias + ReLU).
+//   columns, signs +-1 (uniform per K step), out-of-image pixels read as 0.  The output transform only ever
+//   needs m0 + m3, m1 and m2 + m4 per axis, so the positions {0,3} and {2,4} of an axis are concatenated along
+//   K: blockIdx.y selects one of 3 x 3 sums q = (qi, qj), whose K loop walks its 4, 2 or 1 positions (heaviest
+//   sums first) -- 9 result tensors instead of 25.  H, W = the input image, Ho, Wo = the tile grid (th, tw),
+//   M = T.  wt = the 16 distinct weight matrices U[4 min(pr,3) + min(pc,3)][Cin][Cout]; raw stores to
+//   out[q][T][Cout] (wino_s2_output finishes A^T m A, + bias, ReLU).
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int STRIDE, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restrict__ in,
@@ -181,17 +184,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     constexpr int TAPS = (MODE == 1 || MODE == 3) ? 1 : 9;
     const int p0 = bm * BM;                          // first output pixel (MODE 3: tile) of this block (< M)
     const long long b0 = MODE != 1 ? (p0 / Wo) / Ho : 0;   // its window
-    // MODE 3: the terms of this block's position.  Row transform B^T = [d0 - d2, d2, d4 - d2, d1, d3]: first patch row
-    // (always), second patch row (-1: none; it enters with a minus sign); the same for columns.
-    int s3r0 = 0, s3r1 = -1, s3c0 = 0, s3c1 = -1;
+    // MODE 3: this block's sum q = (qi, qj): axis index 0 = positions {0, 3}, 1 = {1}, 2 = {2, 4}
+    int s3qi = 1, s3qj = 1, s3sh = 0, s3np = 1;
+    int st_sp = 0, st_c0 = 0;   // MODE 3: position (within the block's sum) and first channel of the tile being staged
+    int st_r0 = 0, st_r1 = -1, st_cs0 = 0, st_cs1 = -1, st_tap = 0;   // ... and that position's terms and weight matrix
     if (MODE == 3) {
-        const int pr = (int)blockIdx.y / 5, pc = (int)blockIdx.y - 5 * pr;
-        s3r0 = pr == 0 ? 0 : pr == 1 ? 2 : pr == 2 ? 4 : pr == 3 ? 1 : 3;
-        s3r1 = (pr == 0 || pr == 2) ? 2 : -1;
-        s3c0 = pc == 0 ? 0 : pc == 1 ? 2 : pc == 2 ? 4 : pc == 3 ? 1 : 3;
-        s3c1 = (pc == 0 || pc == 2) ? 2 : -1;
-        wt += (size_t)(4 * (pr < 3 ? pr : 3) + (pc < 3 ? pc : 3)) * Cin * Cout;
-        out += (size_t)blockIdx.y * M * Cout;
+        const int q = (int)((0x471356280ull >> (4 * blockIdx.y)) & 15);   // blockIdx.y -> q: 0,8,2,6 (K = 4 Cin), 5,3,1,7 (2 Cin), 4 (Cin)
+        s3qi = q / 3;
+        s3qj = q - 3 * s3qi;
+        s3sh = s3qj == 1 ? 0 : 1;   // two column positions: position index = 2 ri + ci
+        s3np = (s3qi == 1 ? 1 : 2) << s3sh;
+        out += (size_t)q * M * Cout;
     }
     if (MODE == 1) {                                 // batched GEMM: this block's problem
         in += (size_t)blockIdx.y * M * Cin;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     const unsigned bs_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(&Bs[0][0] + wave * (64 / BCH) * BN));
 
     const int cchunks = Cin / BK;
-    const int KT = TAPS * cchunks;
+    const int KT = (MODE == 3 ? s3np : TAPS) * cchunks;
     // K steps of this block: all of them, or this split's share (gridDim.y <= KT, host-checked)
     // (MODE 1: the split is blockIdx.z, one-clip engines only; wino_output_f2 adds the copies in split order)
     const int ks = MODE == 2 ? (int)blockIdx.y : MODE == 1 ? (int)blockIdx.z : 0;
@@ -280,9 +283,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     // -17 %).  Narrow layers (Cin = 32: one pixel = one 128-B line = two chunks) keep tap-major order,
     // which reads both halves of a line in consecutive K steps (the other order fetched 30 % more).
     const bool dx_inner = MODE != 1 && MODE != 3 && cchunks >= 8;
+    // MODE 3: K step -> position (pr, pc) of the block's sum and channel chunk; the position's terms: row transform
+    // B^T = [d0 - d2, d2, d4 - d2, d1, d3] = first patch row (always) and second patch row (-1: none; it enters with a
+    // minus sign); the same for columns.  tap_ = the position's weight matrix.
+#define APR_S3_DECODE(KT_)                                                                               \
+        const int c0_ = st_c0, s3r0 = st_r0, s3r1 = st_r1, s3c0 = st_cs0, s3c1 = st_cs1, tap_ = st_tap;  \
+        (void)s3r0; (void)s3r1; (void)s3c0; (void)s3c1; (void)tap_;
+    // (the staged tile's position changes every Cin / BK steps: decoded there, not in every step)
+#define APR_S3_POSITION()                                                                                \
+    {                                                                                                    \
+        const int ri_ = st_sp >> s3sh, ci_ = st_sp & s3sh;                                               \
+        const int pr_ = s3qi == 1 ? 1 : s3qi == 0 ? (ri_ ? 3 : 0) : (ri_ ? 4 : 2);                       \
+        const int pc_ = s3qj == 1 ? 1 : s3qj == 0 ? (ci_ ? 3 : 0) : (ci_ ? 4 : 2);                       \
+        st_r0 = pr_ == 0 ? 0 : pr_ == 1 ? 2 : pr_ == 2 ? 4 : pr_ == 3 ? 1 : 3;                           \
+        st_r1 = (pr_ == 0 || pr_ == 2) ? 2 : -1;                                                         \
+        st_cs0 = pc_ == 0 ? 0 : pc_ == 1 ? 2 : pc_ == 2 ? 4 : pc_ == 3 ? 1 : 3;                          \
+        st_cs1 = (pc_ == 0 || pc_ == 2) ? 2 : -1;                                                        \
+        st_tap = 4 * (pr_ < 3 ? pr_ : 3) + (pc_ < 3 ? pc_ : 3);                                          \
+    }
 #define APR_KT_SPLIT(KT_)                                                                                \
         int tap_, c0_;                                                                                   \
-        if (dx_inner) {                                                                                  \
+        if (MODE == 3) {                                                                                 \
+            c0_ = st_c0;                                                                                 \
+            tap_ = st_tap;                                                                               \
+        } else if (dx_inner) {                                                                                  \
             const int dy_ = (KT_) / (3 * cchunks);                                                       \
             const int rem_ = (KT_) - dy_ * 3 * cchunks;                                                  \
             const int cc_ = rem_ / 3;                                                                    \
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     // the position's absent terms are skipped by block-uniform branches: 49 loads per 25 positions, not 100.
 #define APR_LOAD_A3(KT_, I_)                                                                             \
     {                                                                                                    \
-        const int c0_ = (KT_) * BK;                                                                      \
+        APR_S3_DECODE(KT_)                                                                               \
         const unsigned rk_ = rowmask[I_] & 0xFFu, ck_ = rowmask[I_] >> 8;                                \
         const bool r0_ = (rk_ >> s3r0) & 1u, r1_ = s3r1 >= 0 && ((rk_ >> (s3r1 & 7)) & 1u);              \
         const bool c0k_ = (ck_ >> s3c0) & 1u, c1k_ = s3c1 >= 0 && ((ck_ >> (s3c1 & 7)) & 1u);            \
@@ -338,18 +362,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #define APR_STORE_A(BUF_, I_)                                                                            \
     {                                                                                                    \
         float *a_ = As[BUF_] + ar0 + AR * (I_);                                                          \
-        if (MODE == 3) {   /* (d[r0][c0] - d[r0][c1]) - (d[r1][c0] - d[r1][c1]), absent terms left out */ \
-            if (s3c1 >= 0) ra[I_] -= ra3[0];                                                             \
-            if (s3r1 >= 0) {                                                                             \
-                f32x4 t_ = ra3[1];                                                                       \
-                if (s3c1 >= 0) t_ -= ra3[2];                                                             \
-                ra[I_] -= t_;                                                                            \
-            }                                                                                            \
-        }                                                                                                \
         a_[(ac * 4 + 0) * LDA] = ra[I_].x;                                                               \
         a_[(ac * 4 + 1) * LDA] = ra[I_].y;                                                               \
         a_[(ac * 4 + 2) * LDA] = ra[I_].z;                                                               \
         a_[(ac * 4 + 3) * LDA] = ra[I_].w;                                                               \
+    }
+    // MODE 3: (d[r0][c0] - d[r0][c1]) - (d[r1][c0] - d[r1][c1]) of row I_ of K step KT_, absent terms left out
+#define APR_COMBINE_A3(KT_, I_)                                                                          \
+    {                                                                                                    \
+        APR_S3_DECODE(KT_)                                                                               \
+        (void)c0_;                                                                                       \
+        if (s3c1 >= 0) ra[I_] -= ra3[0];                                                                 \
+        if (s3r1 >= 0) {                                                                                 \
+            f32x4 t_ = ra3[1];                                                                           \
+            if (s3c1 >= 0) t_ -= ra3[2];                                                                 \
+            ra[I_] -= t_;                                                                                \
+        }                                                                                                \
     }
 #define APR_STORE_B(BUF_, I_) *reinterpret_cast<f32x4 *>(Bs[BUF_] + (brow0 + BROWS * (I_)) * BN + bch * 4) = rb[I_];
 
@@ -361,11 +389,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
+    if (MODE == 3) APR_S3_POSITION()
     APR_LOAD_TILES(kt0)
     if (APR_EXP_BDMA) APR_DMA_B(kt0, 0)
     if (MODE == 3) {
 #pragma unroll
-        for (int i = 0; i < AROWS; i++) { APR_LOAD_A3(kt0, i) APR_STORE_A(0, i) }
+        for (int i = 0; i < AROWS; i++) { APR_LOAD_A3(kt0, i) APR_COMBINE_A3(kt0, i) APR_STORE_A(0, i) }
     } else {
 #pragma unroll
         for (int i = 0; i < AROWS; i++) APR_STORE_A(0, i)
@@ -376,6 +405,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     }
     if (APR_EXP_BDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#define APR_S3_ADVANCE()                                                                                 \
+    if (MODE == 3) {                                                                                     \
+        st_c0 += BK;                                                                                     \
+        if (st_c0 >= Cin) { st_c0 = 0; st_sp++; APR_S3_POSITION() }                                      \
+    }
+    APR_S3_ADVANCE()
 
     // Main loop.  Everything that is not an MFMA is placed in the shadow of the MFMAs: operand
     // fragments are read one k-pair ahead (two register sets); the next tile's buffer loads are
@@ -404,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
             if (MODE == 3 && HAS_NEXT) {   /* row 0: loaded after k-pair 0, stored at 3; row 1: loaded at 3, stored at 6 */ \
                 constexpr int R1 = AROWS > 1 ? 1 : 0;                                                    \
                 if (kk == 0) APR_LOAD_A3(kt + 1, 0)                                                      \
-                if (kk == 3) { APR_STORE_A(cur ^ 1, 0) if (AROWS > 1) APR_LOAD_A3(kt + 1, R1) }          \
-                if (AROWS > 1 && kk == 6) APR_STORE_A(cur ^ 1, R1)                                       \
+                if (kk == 3) { APR_COMBINE_A3(kt + 1, 0) APR_STORE_A(cur ^ 1, 0) if (AROWS > 1) APR_LOAD_A3(kt + 1, R1) } \
+                if (AROWS > 1 && kk == 6) { APR_COMBINE_A3(kt + 1, R1) APR_STORE_A(cur ^ 1, R1) }        \
             }                                                                                            \
             if (APR_EXP_STAGE && APR_EXP_STORE && !APR_EXP_BDMA && HAS_NEXT && kk >= ST0 && kk < ST0 + BPASS) APR_STORE_B(cur ^ 1, kk - ST0) \
             if (APR_EXP_STAGE && !APR_EXP_STORE && HAS_NEXT && kk == ST0) {                              \
@@ -420,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
         if (APR_EXP_BDMA && HAS_NEXT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   \
         if (APR_EXP_SYNC) __syncthreads();                                                               \
         cur ^= 1;                                                                                        \
+        APR_S3_ADVANCE()                                                                                 \
     }
 
     int cur = 0;
@@ -427,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
     for (; kt < kt1 - 1; kt++) APR_KSTEP(true)
     APR_KSTEP(false)
 #undef APR_KSTEP
+#undef APR_S3_ADVANCE
+#undef APR_S3_POSITION
 
     // ---- epilogue: bias + ReLU, NHWC store.  D[row][col]: col = lane&31,
     //      row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
@@ -459,6 +497,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_igemm_f32(const float *__restr
 
 #undef APR_LOAD_TILES
 #undef APR_LOAD_A3
+#undef APR_COMBINE_A3
+#undef APR_S3_DECODE
 #undef APR_KT_SPLIT
 #undef APR_STORE_A
 #undef APR_STORE_B

@@ -304,11 +304,11 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     // APR_WINO_S2=0 turns it off; APR_WINO_S2_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests).
     const char *s2env = getenv("APR_WINO_S2");
     const bool wino_s2_on = wino_on && !(s2env && s2env[0] == '0');
-    // Passes of >= 1024 windows: layers 8 and 10 (Cin 512, >= 24 pixels a window; measured 100.6 vs 115.5 and 25.3 vs 29.4 ms a
-    // step; layer 6 loses 4 ms, layer 12 pads 2x3 pixels to 2x4).  Passes of 128..1023 windows (live mode): layers 6 to 12 --
-    // there the direct kernel's grids are short (layer 12 at 256 windows: 192 workgroups of 576 K steps, 620 us against 260).
+    // Passes of >= 1024 windows: layers 6, 8 and 10 (Cin >= 256, >= 24 pixels a window; measured 105.6 vs 116.4, 95.4 vs 115.5
+    // and 24.1 vs 29.4 ms a step; layer 4 loses 10 ms, layer 12 pads 2x3 pixels to 2x4).  Passes of 128..1023 windows (live
+    // mode): layers 6 to 12 -- there the direct kernel's grids are short (layer 12 at 256 windows: 192 workgroups of 576 K steps).
     const bool s2_big = e->max_batch >= 1024;
-    const int wino_s2_min_cin = getenv("APR_WINO_S2_MIN_CIN") ? atoi(getenv("APR_WINO_S2_MIN_CIN")) : (s2_big ? 512 : 256);
+    const int wino_s2_min_cin = getenv("APR_WINO_S2_MIN_CIN") ? atoi(getenv("APR_WINO_S2_MIN_CIN")) : 256;
     const int wino_s2_min_px = getenv("APR_WINO_S2_MIN_PX") ? atoi(getenv("APR_WINO_S2_MIN_PX")) : (s2_big ? 24 : 1);
     const int wino_s2_min_batch = getenv("APR_WINO_S2_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_MIN_BATCH")) : 128;
     const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
@@ -401,8 +401,8 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             L.th = (L.hout + 1) / 2;
             L.tw = (L.wout + 1) / 2;
             const long long t_full = (long long)e->max_batch * L.th * L.tw;
-            L.wbm_tile = ((t_full + 127) / 128) * (cv.cout / 128) * 25 < 1024 ? 64 : 128;
-            m_max = std::max(m_max, (size_t)25 * L.th * L.tw * cv.cout);
+            L.wbm_tile = ((t_full + 127) / 128) * (cv.cout / 128) * 9 < 1024 ? 64 : 128;
+            m_max = std::max(m_max, (size_t)9 * L.th * L.tw * cv.cout);
         }
         act_max = std::max(act_max, (size_t)L.cout * L.hout * L.wout);
         h = L.hout; w = L.wout;
@@ -567,17 +567,17 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             const long long nm = T * (L.cout / 4);
             {
                 ProfScope ps(e, L.slot, 2.0 * 25.0 * (double)T * L.cin * L.cout,
-                             4.0 * ((double)batch * L.hin * L.win * L.cin + 25.0 * (double)T * L.cout + 16.0 * L.cin * L.cout));
+                             4.0 * ((double)batch * L.hin * L.win * L.cin + 9.0 * (double)T * L.cout + 16.0 * L.cin * L.cout));
                 const int tiles_n = L.cout / 128;
                 if (L.wbm_tile == 64)
-                    hipLaunchKernelGGL((conv3x3_igemm_f32<64, 128, 1, 3>), dim3((unsigned)(((T + 63) / 64) * tiles_n), 25), dim3(256), 0, e->stream, in,
+                    hipLaunchKernelGGL((conv3x3_igemm_f32<64, 128, 1, 3>), dim3((unsigned)(((T + 63) / 64) * tiles_n), 9), dim3(256), 0, e->stream, in,
                                        L.d_u, L.d_b, e->d_M, L.hin, L.win, L.cin, L.th, L.tw, L.cout, (int)T, tiles_n);
                 else
-                    hipLaunchKernelGGL((conv3x3_igemm_f32<128, 128, 1, 3>), dim3((unsigned)(((T + 127) / 128) * tiles_n), 25), dim3(256), 0, e->stream, in,
+                    hipLaunchKernelGGL((conv3x3_igemm_f32<128, 128, 1, 3>), dim3((unsigned)(((T + 127) / 128) * tiles_n), 9), dim3(256), 0, e->stream, in,
                                        L.d_u, L.d_b, e->d_M, L.hin, L.win, L.cin, L.th, L.tw, L.cout, (int)T, tiles_n);
             }
             {
-                ProfScope ps(e, L.slot_out, 0.0, 4.0 * (25.0 * T * L.cout + (double)M * L.cout));
+                ProfScope ps(e, L.slot_out, 0.0, 4.0 * (9.0 * T * L.cout + (double)M * L.cout));
                 hipLaunchKernelGGL(wino_s2_output, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
                                    e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
             }

@@ -10,8 +10,11 @@
 //     y = A^T m :  y0 = m0 + m1 + m3,   y1 = m1 + m2 + m4
 // In two dimensions 25 products per 2x2 outputs instead of 36 (1.44x fewer MFMAs), with 16 distinct weight
 // matrices.  tools/wino_s2_check.py: fp32 error 4e-7..6e-7 against 3e-7..4e-7 of the direct form.
-//   conv3x3_igemm_f32<BM, BN, 1, 3>  25 GEMMs [T x Cin] x [Cin x Cout], the input transform formed in its A loader
-//   wino_s2_output                   M[25][T][Cout] -> out NHWC, A^T m A + bias + ReLU
+// The output transform only needs s0 = m0 + m3, s1 = m1, s2 = m2 + m4 per axis (y0 = s0 + s1, y1 = s1 + s2), and a
+// sum of products over positions is one product over the concatenated K: the GEMM kernel accumulates the 25
+// products into 3 x 3 sums S[qi][qj] (K = 4, 2 or 1 times Cin), so only 9 tensors go through HBM.
+//   conv3x3_igemm_f32<BM, BN, 1, 3>  the 9 sums [T x k Cin] x [k Cin x Cout], the input transform formed in its A loader
+//   wino_s2_output                   S[9][T][Cout] -> out NHWC: Y[a][b] = sum of the 2 x 2 block of S at (a, b), + bias, ReLU
 // U is computed on the host in f64 and rounded once (wino_s2_pack_u).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -20,7 +23,7 @@
 
 namespace apr {
 
-// M [25][T][C] -> out [B][Ho][Wo][C]; tile t = (b, ty, tx) holds outputs (2ty..2ty+1, 2tx..2tx+1).
+// S [9][T][C] -> out [B][Ho][Wo][C]; tile t = (b, ty, tx) holds outputs (2ty..2ty+1, 2tx..2tx+1).
 // One thread = one tile x 4 channels.
 __global__ __launch_bounds__(256) void wino_s2_output(const float *__restrict__ Mx, const float *__restrict__ bias,
                                                       float *__restrict__ out, int Ho, int Wo, int C, int th, int tw,
@@ -35,17 +38,17 @@ __global__ __launch_bounds__(256) void wino_s2_output(const float *__restrict__ 
         const long long r = t / tw;
         const int ty = (int)(r % th);
         const long long b = r / th;
-        f32x4 m[5][5];
+        f32x4 m[3][3];
 #pragma unroll
-        for (int i = 0; i < 5; i++)
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 5; j++) m[i][j] = ld4(Mx + ((long long)(5 * i + j) * T + t) * C + c);
-        // rows: tmp = A^T m  (2 x 5),  A^T = [1 1 0 1 0; 0 1 1 0 1]
-        f32x4 tmp[2][5];
+            for (int j = 0; j < 3; j++) m[i][j] = ld4(Mx + ((long long)(3 * i + j) * T + t) * C + c);
+        // rows: tmp[a] = s[a] + s[a + 1]
+        f32x4 tmp[2][3];
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            tmp[0][j] = m[0][j] + m[1][j] + m[3][j];
-            tmp[1][j] = m[1][j] + m[2][j] + m[4][j];
+        for (int j = 0; j < 3; j++) {
+            tmp[0][j] = m[0][j] + m[1][j];
+            tmp[1][j] = m[1][j] + m[2][j];
         }
         const f32x4 bv = ld4(bias + c);
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -53,8 +56,8 @@ __global__ __launch_bounds__(256) void wino_s2_output(const float *__restrict__ 
         for (int i = 0; i < 2; i++) {
             const int y = 2 * ty + i;
             if (y >= Ho) continue;
-            f32x4 y0 = tmp[i][0] + tmp[i][1] + tmp[i][3] + bv;
-            f32x4 y1 = tmp[i][1] + tmp[i][2] + tmp[i][4] + bv;
+            f32x4 y0 = tmp[i][0] + tmp[i][1] + bv;
+            f32x4 y1 = tmp[i][1] + tmp[i][2] + bv;
             y0 = __builtin_elementwise_max(y0, zero);
             y1 = __builtin_elementwise_max(y1, zero);
             float *o = out + ((b * Ho + y) * (long long)Wo + 2 * tx) * C + c;
