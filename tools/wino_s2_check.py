@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Numerical check (numpy, f32 vs f64) of the polyphase Winograd F(2,2) form of the stride-2 3x3 convolution
-(pad 1) that DESIGN.md section 7 proposes for layers 4, 6, 8, 10 -- developer tool, not product code.
+(pad 1) that apr_amd/csrc/wino_s2.hip.h implements (layers 6, 8, 10) -- developer tool, not product code.
 
     out[y][x] = sum_{dy,dx} w[dy][dx] in[2y + dy - 1][2x + dx - 1]
 
