@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void wino_s2_output(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
-            for (int j = 0; j < 3; j++) m[i][j] = ld4(Mx + ((long long)(3 * i + j) * T + t) * C + c);
+            for (int j = 0; j < 3; j++) m[i][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(Mx + ((long long)(3 * i + j) * T + t) * C + c));   // read once
         // rows: tmp[a] = s[a] + s[a + 1]
         f32x4 tmp[2][3];
 #pragma unroll
