@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <map>
 
 namespace apr {
@@ -178,6 +179,8 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
             if (!get(n.in[1], 0, w)) return false;
             if (w->dims.size() != 4 || w->dims[2] != 3 || w->dims[3] != 3) { err = "Conv kernel is not 3x3"; return false; }
             ConvSpec c;
+            // widths are bounded before the int casts: the reference's widest layer is 1024 (ai/model.py:98-103)
+            if (w->dims[0] < 1 || w->dims[0] > kMaxConvWidth || w->dims[1] < 1 || w->dims[1] > kMaxConvWidth) { err = "Conv width out of range (1.." + std::to_string(kMaxConvWidth) + ")"; return false; }
             c.cout = (int)w->dims[0];
             c.cin = (int)w->dims[1];
             if (w->data.size() != (size_t)c.cout * c.cin * 9) { err = "Conv weight size mismatch"; return false; }
@@ -225,7 +228,11 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
             if (w->dims.size() != 2) { err = "Gemm weight is not 2-D"; return false; }
             auto tb = n.i.find("transB");
             bool transB = tb != n.i.end() && tb->second != 0;
+            // dims are checked as int64 (a huge product must not reach resize()) and against the payload
+            const int64_t cls64 = transB ? w->dims[0] : w->dims[1], feat64 = transB ? w->dims[1] : w->dims[0];
+            if (cls64 < 1 || cls64 > kMaxClasses || feat64 < 1 || feat64 > kMaxConvWidth) { err = "Gemm shape out of range (classes 1.." + std::to_string(kMaxClasses) + ", features 1.." + std::to_string(kMaxConvWidth) + ")"; return false; }
             int d0 = (int)w->dims[0], d1 = (int)w->dims[1];
+            if (w->data.size() != (size_t)d0 * (size_t)d1) { err = "Gemm weight size does not match its dims"; return false; }
             out.n_classes = transB ? d0 : d1;
             out.features = transB ? d1 : d0;
             out.fc_w.resize((size_t)d0 * d1);
@@ -262,7 +269,7 @@ bool parse_aprw(const uint8_t *bytes, size_t n, ParsedModel &out, std::string &e
     size_t want = 0;
     for (int l = 0; l < 12; l++) want += (size_t)COUT[l] * CIN[l] * 9 + 5 * (size_t)COUT[l];
     want += (size_t)ncls * 1024 + ncls;
-    if (ncls < 1 || n != 16 + want * 4) { err = "APRW blob size does not match its class count"; return false; }
+    if (ncls < 1 || ncls > (uint32_t)kMaxClasses || n != 16 + want * 4) { err = "APRW blob size does not match its class count"; return false; }
     std::vector<float> f(want);
     memcpy(f.data(), bytes + 16, want * 4);
     const float *p = f.data();
@@ -299,14 +306,20 @@ bool parse_model(const void *bytes, size_t n, ParsedModel &out, std::string &err
     const uint8_t *b = (const uint8_t *)bytes;
     out = ParsedModel();
     bool ok;
-    if (n >= 4 && memcmp(b, "APRW", 4) == 0) ok = parse_aprw(b, n, out, err);
-    else ok = parse_onnx(b, n, out, err);
+    try {   // no exception may cross the C ABI (include/apr.h): an allocation failure inside the parser is a bad model
+        if (n >= 4 && memcmp(b, "APRW", 4) == 0) ok = parse_aprw(b, n, out, err);
+        else ok = parse_onnx(b, n, out, err);
+    } catch (const std::exception &ex) {
+        err = std::string("parser ran out of memory or failed: ") + ex.what();
+        return false;
+    }
     if (!ok) return false;
     // chain consistency: channel counts must follow on, first layer is single channel
     int c = 1;
     for (size_t l = 0; l < out.convs.size(); l++) {
         const ConvSpec &cv = out.convs[l];
         if (cv.cin != c) { err = "conv layer " + std::to_string(l) + " input channels do not follow on"; return false; }
+        if (cv.cin < 1 || cv.cout < 1) { err = "conv layer " + std::to_string(l) + " has no channels"; return false; }
         if (cv.stride != 1 && cv.stride != 2) { err = "conv stride must be 1 or 2"; return false; }
         c = cv.cout;
     }

@@ -8,6 +8,9 @@
 
 namespace apr {
 
+constexpr int kMaxConvWidth = 4096;   // channels of one conv layer / features of the classifier (the reference's widest is 1024)
+constexpr int kMaxClasses = 64;       // = APR_MAX_CLASSES (include/apr.h)
+
 struct ConvSpec {
     int cin = 0, cout = 0, stride = 1;
     std::vector<float> w;   // [cout][cin][3][3], BatchNorm folded in

@@ -86,13 +86,41 @@ def daemon_match_line(name: str, best_class: str, conf: float) -> str:
 # ----------------------------------------------------------------------------------------------
 # multi-process gather (one process per GPU)
 # ----------------------------------------------------------------------------------------------
-def gather_scores(probs, label, counts: Sequence[int], dist=None, dst: int = 0):
-    """Gather per-window score rows of every rank on ``dst``.
+def row_bytes(n_classes: int) -> int:
+    """One gathered score row: C float64 probabilities, the int32 label, the u8 match flag."""
+    return 8 * n_classes + 5
 
-    probs [n_local, C] float64 and label [n_local] int32 are torch tensors on the rank's device;
-    ``counts[r]`` is rank r's window count (known to every rank from the deterministic file
-    partition, so no sizes are exchanged).  Rows are padded to max(counts) for one equal-size
-    all_gather (RCCL's native shape).  Returns (probs_list, label_list) on dst, else (None, None).
+
+def pack_rows(probs, label, match, cap: Optional[int] = None):
+    """[n, 8C+5] uint8 rows (zero-padded to ``cap`` rows): the exact bytes of probs / label / match."""
+    import torch
+    n, C = probs.shape
+    cap = n if cap is None else cap
+    rows = torch.zeros((cap, row_bytes(C)), dtype=torch.uint8, device=probs.device)
+    rows[:n, : 8 * C] = probs.contiguous().view(torch.uint8).reshape(n, 8 * C)
+    rows[:n, 8 * C: 8 * C + 4] = label.contiguous().view(torch.uint8).reshape(n, 4)
+    rows[:n, 8 * C + 4] = match
+    return rows
+
+
+def unpack_rows(rows, n_classes: int):
+    import torch
+    C = n_classes
+    n = rows.shape[0]
+    probs = rows[:, : 8 * C].contiguous().view(torch.float64).reshape(n, C)
+    label = rows[:, 8 * C: 8 * C + 4].contiguous().view(torch.int32).reshape(n)
+    return probs, label, rows[:, 8 * C + 4].contiguous()
+
+
+def gather_scores(probs, label, match, counts: Sequence[int], dist=None, dst: int = 0):
+    """Gather the per-window score rows of every rank on ``dst``: the one exchange of the sweep.
+
+    probs [n_local, C] float64, label [n_local] int32 and match [n_local] uint8 are torch tensors
+    on the rank's device; ``counts[r]`` is rank r's window count (known to every rank from the
+    deterministic file partition, so no sizes are exchanged).  Rows travel as packed bytes
+    (``row_bytes(C)`` each), padded to max(counts): one equal-size gather to the root -- over xGMI
+    every sender uses its own direct link to ``dst``.  Returns three lists (one entry per rank) on
+    dst, (None, None, None) elsewhere.
     """
     import torch
     if dist is None:
@@ -100,20 +128,42 @@ def gather_scores(probs, label, counts: Sequence[int], dist=None, dst: int = 0):
     world = dist.get_world_size()
     rank = dist.get_rank()
     if world == 1:
-        return [probs], [label]
+        return [probs], [label], [match]
+    if len(counts) != world or probs.shape[0] != counts[rank]:
+        raise ValueError("gather_scores: counts must list every rank's rows")
     C = probs.shape[1]
     cap = int(max(counts))
-    packed = torch.zeros((cap, C + 1), dtype=torch.float64, device=probs.device)
-    n = probs.shape[0]
-    packed[:n, :C] = probs
-    packed[:n, C] = label.to(torch.float64)
-    out = torch.empty((world * cap, C + 1), dtype=torch.float64, device=probs.device)
-    dist.all_gather_into_tensor(out, packed)
+    packed = pack_rows(probs, label, match, cap)
+    bufs = [torch.empty_like(packed) for _ in range(world)] if rank == dst else None
+    dist.gather(packed, bufs, dst=dst)
     if rank != dst:
-        return None, None
-    out = out.view(world, cap, C + 1)
-    return ([out[r, : counts[r], :C] for r in range(world)],
-            [out[r, : counts[r], C].to(torch.int32) for r in range(world)])
+        return None, None, None
+    out = [unpack_rows(bufs[r][: counts[r]], C) for r in range(world)]
+    return [o[0] for o in out], [o[1] for o in out], [o[2] for o in out]
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE config 3: a directory of equal-length recordings swept by `world` ranks
+# (the loop of ai/inspect.py:20-70 over a directory, sharded by file: SURVEY 8(d)/(e))
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class ShardPlan:
+    files: List[int]            # this rank's recordings (global file indices), in scoring order
+    plan: StreamPlan            # its recordings laid end to end
+    counts: List[int]           # stream windows of every rank (what gather_scores needs)
+    valid_total: int            # valid windows of the whole job
+
+
+def plan_shards(n_files: int, seconds: int, world: int, rank: int) -> ShardPlan:
+    counts, valid_total, mine = [], 0, None
+    for r in range(world):
+        files = shard_files(n_files, world, r)
+        p = plan_stream([seconds * BYTES_PER_SECOND] * len(files), files)
+        counts.append(p.n_windows)
+        valid_total += p.n_valid
+        if r == rank:
+            mine = (files, p)
+    return ShardPlan(mine[0], mine[1], counts, valid_total)
 
 
 # ----------------------------------------------------------------------------------------------
