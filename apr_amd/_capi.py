@@ -13,6 +13,7 @@ ERR_INVALID, ERR_DEVICE, ERR_MODEL, ERR_NOMEM, ERR_NOMODEL = -1, -2, -3, -4, -5
 FLAVOUR_GO, FLAVOUR_LIBROSA = 0, 1
 WARN_UNDERFLOW, WARN_OVERFLOW = 1, 2
 PROF_SLOTS = 48
+STATIC_MAX_WINDOWS = 64
 
 # every symbol include/apr.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -22,6 +23,7 @@ SYMBOLS = (
     "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
     "apr_resample_taps", "apr_upsample", "apr_upsample_device", "apr_stream_tick", "apr_stream_buffer", "apr_stream_reset",
+    "apr_prepare_batch_device_static",
 )
 
 
@@ -47,6 +49,16 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m apr_amd.build` (hipcc, gfx950). "
             "apr_amd has no CPU fallback.")
+    # PyTorch ships a HIP runtime of its own, and the runtime that is mapped first serves the whole process: with
+    # libapr_amd.so (linked against /opt/rocm) mapped first, a later `import torch` finds no GPU.  Callers that hand
+    # torch device tensors to the device-pointer entry points need one shared runtime, so map torch's first when
+    # torch is installed.  Nothing of torch is used here.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, u8p, f32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)
     L.apr_device_count.restype = C.c_int
@@ -73,6 +85,8 @@ def lib():
     L.apr_score_device.restype = C.c_int
     L.apr_prepare_batch_device.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
     L.apr_prepare_batch_device.restype = C.c_int
+    L.apr_prepare_batch_device_static.argtypes = [vp, C.c_int, u8p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
+    L.apr_prepare_batch_device_static.restype = C.c_int
     L.apr_infer_device.argtypes = [vp, f32p, C.c_int, f32p]
     L.apr_infer_device.restype = C.c_int
     L.apr_classify.argtypes = [vp, f32p, C.c_int, C.c_double, C.c_int, f64p, vp, vp, f32p]

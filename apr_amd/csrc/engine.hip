@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,7 +27,32 @@
 
 using namespace apr;
 
+// ---- apr_prepare_batch_device_static: the front end's one scratch buffer (mel power, frame-major
+// [window][188][128] f32) as a file-scope device array, so that the call allocates nothing.  Every GPU the library
+// runs on holds its own copy (5.9 MiB) until the process ends.  In host code `scratch` is only a stand-in for the
+// symbol: the device address is asked for once per device (hipGetSymbolAddress, at engine creation, with that
+// device current) and kept in g_scratch_ptr; kernels and host calls only ever see that pointer.
+static __device__ __align__(256) float scratch[(size_t)APR_STATIC_MAX_WINDOWS * kSpecFrames * kNmels];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+float *g_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_scratch_mu;
+
+// with `device` current; returns nullptr (and leaves the slot empty) on failure
+float *resolve_scratch(int device, std::string &err)
+{
+    if (device < 0 || device >= kMaxDevices) { err = "device index beyond the static-scratch table"; return nullptr; }
+    std::lock_guard<std::mutex> g(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        float *ptr = nullptr;
+        const hipError_t r = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+        if (r != hipSuccess || !ptr) { err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(r); return nullptr; }
+        g_scratch_ptr[device] = ptr;
+    }
+    return g_scratch_ptr[device];
+}
 
 thread_local std::string g_create_err;
 
@@ -476,22 +502,24 @@ int prof_flush(apr_engine *e)
 }
 
 // ---- launches ---------------------------------------------------------------------------------
+// melT: the mel-power scratch of this launch pair (the engine's own d_melT, or the static array of the allocation-free entry)
 int run_frontend(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes, int n_windows, size_t stride,
-                 float *d_out)
+                 float *d_out, float *melT = nullptr, bool timed = true)
 {
+    if (!melT) melT = e->d_melT;
     const FrontendTables &T = e->tab[flavour];
     const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
     // a handful of windows (live clips): db_norm gets one block per 32-frame column chunk instead of one per
     // window, so its latency is a sixth; the arithmetic per element is the same code
     const bool few = n_windows <= 8;
     {
-        ProfScope ps(e, 0, (double)n_windows * T.n_frames * 5.0 * kNfft * 11.0 + 2.0 * T.nnz * T.n_frames * n_windows,
+        ProfScope ps(e, timed ? 0 : -1, (double)n_windows * T.n_frames * 5.0 * kNfft * 11.0 + 2.0 * T.nnz * T.n_frames * n_windows,
                      (double)n_windows * (std::min<size_t>(stride, APR_SAMPLE_SIZE) + (double)T.n_frames * kNmels * 4));
-        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, e->d_melT);
+        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, melT);
     }
     {
-        ProfScope ps(e, 1, 0.0, (double)n_windows * ((double)T.n_frames * kNmels * 4 + APR_SPEC_ELEMS * 4));
-        hipLaunchKernelGGL(db_norm_kernel, dim3(n_windows, few ? 6 : 1), dim3(256), 0, e->stream, e->d_melT, n_windows, T.n_frames,
+        ProfScope ps(e, timed ? 1 : -1, 0.0, (double)n_windows * ((double)T.n_frames * kNmels * 4 + APR_SPEC_ELEMS * 4));
+        hipLaunchKernelGGL(db_norm_kernel, dim3(n_windows, few ? 6 : 1), dim3(256), 0, e->stream, melT, n_windows, T.n_frames,
                            T.librosa, d_out);
     }
     HIPCHK(e, hipGetLastError());
@@ -847,6 +875,7 @@ int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_
         rc = APR_ERR_DEVICE;
     }
     if (!rc && (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || e->n_cus < 1)) e->n_cus = 256;
+    if (!rc && !resolve_scratch(device_id, e->err)) rc = APR_ERR_DEVICE;   // this device's address of the static scratch array
     if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(conv12_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C12_LDS_BYTES) != hipSuccess) {
         e->err = "could not reserve LDS for conv12_fused_kernel";
         rc = APR_ERR_DEVICE;
@@ -952,6 +981,28 @@ int apr_prepare_batch_device(apr_engine *e, int flavour, const uint8_t *d_pcm, s
         if ((rc = run_frontend(e, flavour, d_pcm + std::min(off, total_bytes), rem, (int)nw, stride_bytes, d_out + w0 * APR_SPEC_ELEMS))) return rc;
     }
     return APR_OK;
+}
+
+int apr_prepare_batch_device_static(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes, size_t n_windows,
+                                    size_t stride_bytes, float *d_out)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if ((flavour != APR_FLAVOUR_GO && flavour != APR_FLAVOUR_LIBROSA) || (n_windows && (!d_pcm || !d_out)) || (n_windows > 1 && !stride_bytes)) {
+        e->err = "apr_prepare_batch_device_static: bad argument";
+        return APR_ERR_INVALID;
+    }
+    if (n_windows > (size_t)APR_STATIC_MAX_WINDOWS) {
+        e->err = "apr_prepare_batch_device_static: n_windows exceeds APR_STATIC_MAX_WINDOWS (" + std::to_string(APR_STATIC_MAX_WINDOWS) +
+                 "); split the call or use apr_prepare_batch_device";
+        return APR_ERR_INVALID;
+    }
+    if (!n_windows) return APR_OK;
+    float *ptr = e->device < kMaxDevices ? g_scratch_ptr[e->device] : nullptr;   // resolved at apr_engine_create, per device
+    if (!ptr) { e->err = "apr_prepare_batch_device_static: static scratch was not resolved on this device"; return APR_ERR_DEVICE; }
+    // stft_mel_kernel writes every mel-power element db_norm_kernel reads (all n_frames x 128 of each of the n_windows windows),
+    // so the array's previous contents never show: nothing to clear.  No event timing here (events would be allocated).
+    return run_frontend(e, flavour, d_pcm, total_bytes, (int)n_windows, stride_bytes, d_out, ptr, false);
 }
 
 int apr_prepare_batch(apr_engine *e, int flavour, const uint8_t *pcm, size_t total_bytes, size_t n_windows, size_t stride_bytes,

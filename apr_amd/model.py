@@ -247,6 +247,12 @@ class Engine:
         self._chk(self._lib.apr_prepare_batch_device(self._h, flavour, _addr(d_pcm), total_bytes, n_windows, stride,
                                                      _addr(d_out)))
 
+    def prepare_batch_device_static(self, d_pcm, total_bytes: int, n_windows: int, stride: int, d_out,
+                                    flavour: int = FLAVOUR_GO) -> None:
+        """apr_prepare_batch_device_static: the allocation-free form (<= 64 windows; scratch is a static device array)."""
+        self._chk(self._lib.apr_prepare_batch_device_static(self._h, flavour, _addr(d_pcm), total_bytes, n_windows, stride,
+                                                            _addr(d_out)))
+
     def infer_device(self, d_spec, batch: int, d_logits) -> None:
         self._chk(self._lib.apr_infer_device(self._h, _addr(d_spec), batch, _addr(d_logits)))
 

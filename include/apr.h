@@ -175,6 +175,20 @@ int apr_score_device(apr_engine *e, const uint8_t *d_pcm, size_t total_bytes, si
 int apr_prepare_batch_device(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes,
                              size_t n_windows, size_t stride_bytes, float *d_out);
 
+/*
+ * apr_prepare_batch_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  NO COUNTERPART IN THE REFERENCE.  Same arguments, same kernels and bit-identical
+ * output; the front end's one scratch buffer (mel power, [n_windows][188][128] f32) is a file-scope device array of
+ * the library instead of engine memory, and the call itself performs no hipMalloc / hipFree / event creation (the
+ * engine was created earlier, outside such a region).  Limit: n_windows <= APR_STATIC_MAX_WINDOWS, larger calls
+ * are rejected with APR_ERR_INVALID (no chunking: split the call).  Every GPU the library runs on holds one copy of
+ * the array (5.9 MiB) until the process ends, and EVERY engine on a GPU shares it: two calls that overlap on one GPU
+ * (two engines, two streams) race.  Asynchronous on the engine's stream.
+ */
+#define APR_STATIC_MAX_WINDOWS 64
+int apr_prepare_batch_device_static(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_bytes,
+                                    size_t n_windows, size_t stride_bytes, float *d_out);
+
 /* Device-resident CNN: d_spec [batch][128][188] -> d_logits [batch][C].  Asynchronous. */
 int apr_infer_device(apr_engine *e, const float *d_spec, int batch, float *d_logits);
 
