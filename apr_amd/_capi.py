@@ -23,7 +23,7 @@ SYMBOLS = (
     "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
     "apr_resample_taps", "apr_upsample", "apr_upsample_device", "apr_stream_tick", "apr_stream_buffer", "apr_stream_reset",
-    "apr_prepare_batch_device_static",
+    "apr_prepare_batch_device_static", "apr_engine_create_ex", "apr_sweep_plan", "apr_sweep_files_multi",
 )
 
 
@@ -98,6 +98,13 @@ def lib():
     L.apr_sweep_files.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_double, C.c_int,
                                   f64p, vp, vp, C.POINTER(C.c_size_t)]
     L.apr_sweep_files.restype = C.c_int
+    L.apr_engine_create_ex.argtypes = [vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    L.apr_engine_create_ex.restype = C.c_int
+    L.apr_sweep_plan.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.c_size_t, C.c_int, vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.apr_sweep_plan.restype = C.c_int
+    L.apr_sweep_files_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                        C.c_double, C.c_int, f64p, vp, vp, C.POINTER(C.c_size_t)]
+    L.apr_sweep_files_multi.restype = C.c_int
     L.apr_wav_data_offset.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
     L.apr_wav_data_offset.restype = C.c_size_t
     L.apr_bucket_hits.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]

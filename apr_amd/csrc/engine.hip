@@ -10,8 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/apr.h"
@@ -136,7 +138,7 @@ struct apr_engine {
     int32_t *d_label2[2] = {nullptr, nullptr};
     uint8_t *d_match2[2] = {nullptr, nullptr};
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
-    size_t pin_cap = 0;
+    size_t pin_cap = 0, pin_want = 0;   // bytes of a complete staging set / bytes the (possibly partial) set was sized for
 
     // Calls of at most 4 windows through the host-pointer entry points (apr_score, apr_infer, apr_prepare[_batch]: the
     // daemon's one-clip-per-call pattern) replay a captured hipGraph -- H2D from pinned staging, every kernel, D2H into
@@ -182,6 +184,17 @@ int dev_alloc(apr_engine *e, T **p, size_t count)
     e->allocs.push_back(q);
     *p = (T *)q;
     return APR_OK;
+}
+
+// release one dev_alloc'd buffer before destroy (buffers that are re-sized between calls)
+template <typename T>
+void dev_free(apr_engine *e, T **p)
+{
+    if (!*p) return;
+    auto it = std::find(e->allocs.begin(), e->allocs.end(), (void *)*p);
+    if (it != e->allocs.end()) e->allocs.erase(it);
+    (void)hipFree(*p);
+    *p = nullptr;
 }
 
 template <typename T>
@@ -845,7 +858,27 @@ int apr_model_info(const void *model_bytes, size_t n, int *n_classes, int *n_con
     return APR_OK;
 }
 
+static int engine_create(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out);
+
 int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out)
+{
+    try {
+        return engine_create(model_bytes, n, device_id, max_batch, out);
+    } catch (const std::exception &ex) {   // host allocation failure in a std container: no exception crosses the C ABI
+        g_create_err = std::string("out of host memory: ") + ex.what();
+        if (out) *out = nullptr;
+        return APR_ERR_NOMEM;
+    }
+}
+
+int apr_engine_create_ex(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out, char *errbuf, size_t errbuf_len)
+{
+    const int rc = apr_engine_create(model_bytes, n, device_id, max_batch, out);
+    if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", rc ? g_create_err.c_str() : "");
+    return rc;
+}
+
+static int engine_create(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out)
 {
     if (!out) return APR_ERR_INVALID;
     *out = nullptr;
@@ -1301,43 +1334,72 @@ size_t apr_windows_in(size_t nbytes, size_t stride_bytes)
     return (nbytes - stride_bytes + stride_bytes - 1) / stride_bytes;
 }
 
-int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const size_t *nbytes, size_t stride_bytes, double trust,
-                    int empty_class, double *probs, int32_t *label, uint8_t *match, size_t *first_window)
+// Staging of the file sweeps: two pinned host buffers + two device buffers + their events, sized for one stride.  Every
+// step is idempotent (null checks), so a call that failed half-way is resumed by the next one instead of leaking; a
+// call with another stride releases the old set first.
+static void sweep_release(apr_engine *e)
 {
-    int rc = check_engine(e);
-    if (rc) return rc;
-    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
-    if (n_files < 0 || (n_files && (!pcm || !nbytes)) || !stride_bytes || stride_bytes % 2) { e->err = "apr_sweep_files: bad argument"; return APR_ERR_INVALID; }
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->copy_stream) (void)hipStreamSynchronize(e->copy_stream);
+    for (int b = 0; b < 2; b++) {
+        if (e->h_pin[b]) { (void)hipHostFree(e->h_pin[b]); e->h_pin[b] = nullptr; }
+        if (e->h_probs[b]) { (void)hipHostFree(e->h_probs[b]); e->h_probs[b] = nullptr; }
+        if (e->h_label[b]) { (void)hipHostFree(e->h_label[b]); e->h_label[b] = nullptr; }
+        if (e->h_match[b]) { (void)hipHostFree(e->h_match[b]); e->h_match[b] = nullptr; }
+        dev_free(e, &e->d_pin[b]);
+        dev_free(e, &e->d_probs2[b]);
+        dev_free(e, &e->d_label2[b]);
+        dev_free(e, &e->d_match2[b]);
+    }
+    e->pin_cap = e->pin_want = 0;
+}
+
+static int sweep_reserve(apr_engine *e, size_t cap_bytes, size_t cap_w)
+{
+    if (e->pin_cap == cap_bytes) return APR_OK;
+    if (e->pin_want && e->pin_want != cap_bytes) sweep_release(e);   // another stride: other buffer sizes
+    e->pin_want = cap_bytes;
+    const int C = e->n_classes;
+    int rc;
+    if (!e->copy_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; b++) {
+        if (!e->h_pin[b]) HIPCHK(e, hipHostMalloc((void **)&e->h_pin[b], cap_bytes, hipHostMallocDefault));
+        if (!e->h_probs[b]) HIPCHK(e, hipHostMalloc((void **)&e->h_probs[b], cap_w * C * sizeof(double), hipHostMallocDefault));
+        if (!e->h_label[b]) HIPCHK(e, hipHostMalloc((void **)&e->h_label[b], cap_w * sizeof(int32_t), hipHostMallocDefault));
+        if (!e->h_match[b]) HIPCHK(e, hipHostMalloc((void **)&e->h_match[b], cap_w, hipHostMallocDefault));
+        if ((!e->d_pin[b] && (rc = dev_alloc(e, &e->d_pin[b], cap_bytes + 16))) || (!e->d_probs2[b] && (rc = dev_alloc(e, &e->d_probs2[b], cap_w * C))) ||
+            (!e->d_label2[b] && (rc = dev_alloc(e, &e->d_label2[b], cap_w))) || (!e->d_match2[b] && (rc = dev_alloc(e, &e->d_match2[b], cap_w))))
+            return rc;
+        if (!e->ev_h2d[b]) HIPCHK(e, hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
+        if (!e->ev_done[b]) HIPCHK(e, hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
+    }
+    e->pin_cap = cap_bytes;                     // only a complete set counts
+    return APR_OK;
+}
+
+// The sweep over the files idx[0..n_idx) of the caller's list (idx == nullptr: files 0..n_files) on one engine; the rows
+// of file f go to row_base[f] + k of probs / label / match.  apr_sweep_files passes every file; apr_sweep_files_multi
+// gives each engine the files of its device.
+static int sweep_files_on(apr_engine *e, const int *idx, int n_idx, const uint8_t *const *pcm, const size_t *nbytes, size_t stride_bytes,
+                          double trust, int empty_class, double *probs, int32_t *label, uint8_t *match, const size_t *row_base)
+{
+    int rc;
     const int C = e->n_classes;
     const size_t span_w = (APR_SAMPLE_SIZE + stride_bytes - 1) / stride_bytes;   // strides one window spans (2 at the 1-s hop)
     const size_t cap_w = (size_t)e->max_batch;                                    // stream windows per pass
     if (span_w > cap_w) { e->err = "apr_sweep_files: stride too small for max_batch"; return APR_ERR_INVALID; }
     const size_t cap_bytes = (cap_w + span_w) * stride_bytes;
-    if (e->pin_cap < cap_bytes) {
-        if (e->pin_cap) { e->err = "apr_sweep_files: stride changed between calls on one engine"; return APR_ERR_INVALID; }
-        HIPCHK(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
-            HIPCHK(e, hipHostMalloc((void **)&e->h_pin[b], cap_bytes, hipHostMallocDefault));
-            HIPCHK(e, hipHostMalloc((void **)&e->h_probs[b], cap_w * C * sizeof(double), hipHostMallocDefault));
-            HIPCHK(e, hipHostMalloc((void **)&e->h_label[b], cap_w * sizeof(int32_t), hipHostMallocDefault));
-            HIPCHK(e, hipHostMalloc((void **)&e->h_match[b], cap_w, hipHostMallocDefault));
-            if ((rc = dev_alloc(e, &e->d_pin[b], cap_bytes + 16)) || (rc = dev_alloc(e, &e->d_probs2[b], cap_w * C)) ||
-                (rc = dev_alloc(e, &e->d_label2[b], cap_w)) || (rc = dev_alloc(e, &e->d_match2[b], cap_w)))
-                return rc;
-            HIPCHK(e, hipEventCreateWithFlags(&e->ev_h2d[b], hipEventDisableTiming));
-            HIPCHK(e, hipEventCreateWithFlags(&e->ev_done[b], hipEventDisableTiming));
-        }
-        e->pin_cap = cap_bytes;
-    }
+    if ((rc = sweep_reserve(e, cap_bytes, cap_w))) return rc;
 
     // segments: [w0, w0 + nw) of one file, laid into a pass at a stride-aligned base; the span_w - 1
     // stream windows after a segment straddle into the next one and are dropped
     struct Seg { int file; size_t w0, nw, base_w, row; };
     std::vector<std::vector<Seg>> passes(1);
-    size_t used = 0, row = 0;
-    for (int f = 0; f < n_files; f++) {
-        if (first_window) first_window[f] = row;
-        size_t W = apr_windows_in(nbytes[f], stride_bytes), w0 = 0;
+    size_t used = 0;
+    for (int i = 0; i < n_idx; i++) {
+        const int f = idx ? idx[i] : i;
+        if (nbytes[f] && !pcm[f]) { e->err = "apr_sweep_files: NULL recording with a non-zero length"; return APR_ERR_INVALID; }
+        size_t W = apr_windows_in(nbytes[f], stride_bytes), w0 = 0, row = row_base[f];
         while (W) {
             const size_t room = cap_w - used;
             if (room < 1) { passes.emplace_back(); used = 0; continue; }
@@ -1348,7 +1410,6 @@ int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const
             w0 += nw; W -= nw; row += nw;
         }
     }
-    if (first_window) first_window[n_files] = row;
     if (passes.back().empty()) passes.pop_back();
 
     auto drain = [&](int b, const std::vector<Seg> &ps) -> int {
@@ -1391,6 +1452,101 @@ int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const
     for (size_t p = passes.size() >= 2 ? passes.size() - 2 : 0; p < passes.size(); p++)
         if ((rc = drain((int)(p & 1), passes[p]))) return rc;
     return APR_OK;
+}
+
+int apr_sweep_plan(int n_files, const size_t *nbytes, size_t stride_bytes, int n_devices, int32_t *file_device, size_t *first_window,
+                   size_t *device_windows)
+{
+    if (n_files < 0 || (n_files && !nbytes) || !stride_bytes || n_devices < 1) return APR_ERR_INVALID;
+    if (device_windows) for (int d = 0; d < n_devices; d++) device_windows[d] = 0;
+    size_t row = 0;
+    for (int f = 0; f < n_files; f++) {
+        const int d = f % n_devices;               // by file, round-robin by index: a window never crosses a shard
+        const size_t w = apr_windows_in(nbytes[f], stride_bytes);
+        if (file_device) file_device[f] = d;
+        if (first_window) first_window[f] = row;
+        if (device_windows) device_windows[d] += w;
+        row += w;
+    }
+    if (first_window) first_window[n_files] = row;
+    return APR_OK;
+}
+
+int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const size_t *nbytes, size_t stride_bytes, double trust,
+                    int empty_class, double *probs, int32_t *label, uint8_t *match, size_t *first_window)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (e->layers.empty()) { e->err = "engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+    if (n_files < 0 || (n_files && (!pcm || !nbytes)) || !stride_bytes || stride_bytes % 2) { e->err = "apr_sweep_files: bad argument"; return APR_ERR_INVALID; }
+    try {
+        std::vector<size_t> first((size_t)n_files + 1);
+        if ((rc = apr_sweep_plan(n_files, nbytes, stride_bytes, 1, nullptr, first.data(), nullptr))) return rc;
+        if (first_window) memcpy(first_window, first.data(), first.size() * sizeof(size_t));
+        return sweep_files_on(e, nullptr, n_files, pcm, nbytes, stride_bytes, trust, empty_class, probs, label, match, first.data());
+    } catch (const std::exception &ex) {
+        e->err = std::string("apr_sweep_files: out of host memory: ") + ex.what();
+        return APR_ERR_NOMEM;
+    }
+}
+
+int apr_sweep_files_multi(apr_engine *const *engines, int n_engines, int n_files, const uint8_t *const *pcm, const size_t *nbytes,
+                          size_t stride_bytes, double trust, int empty_class, double *probs, int32_t *label, uint8_t *match,
+                          size_t *first_window)
+{
+    if (!engines || n_engines < 1 || !engines[0]) return APR_ERR_INVALID;
+    apr_engine *e0 = engines[0];
+    for (int i = 0; i < n_engines; i++) {
+        if (!engines[i]) { e0->err = "apr_sweep_files_multi: NULL engine in the list"; return APR_ERR_INVALID; }
+        if (engines[i]->layers.empty()) { e0->err = "apr_sweep_files_multi: engine has no model (front-end only)"; return APR_ERR_NOMODEL; }
+        if (engines[i]->n_classes != e0->n_classes) { e0->err = "apr_sweep_files_multi: the engines hold models with different class counts"; return APR_ERR_INVALID; }
+        for (int j = 0; j < i; j++)
+            if (engines[j] == engines[i]) { e0->err = "apr_sweep_files_multi: the same engine is listed twice (a handle serves one caller at a time)"; return APR_ERR_INVALID; }
+    }
+    if (n_files < 0 || (n_files && (!pcm || !nbytes)) || !stride_bytes || stride_bytes % 2) { e0->err = "apr_sweep_files_multi: bad argument"; return APR_ERR_INVALID; }
+    try {
+        std::vector<size_t> first((size_t)n_files + 1);
+        std::vector<int32_t> dev((size_t)std::max(n_files, 1));
+        int rc = apr_sweep_plan(n_files, nbytes, stride_bytes, n_engines, dev.data(), first.data(), nullptr);
+        if (rc) return rc;
+        if (first_window) memcpy(first_window, first.data(), first.size() * sizeof(size_t));
+        std::vector<std::vector<int>> mine((size_t)n_engines);
+        for (int f = 0; f < n_files; f++) mine[(size_t)dev[f]].push_back(f);
+        // one host thread per engine: each binds its engine's GPU (check_engine), stages its own files through its own
+        // pinned buffers and writes its rows straight into the caller's arrays (disjoint rows: no gather step on the host)
+        std::vector<int> rcs((size_t)n_engines, APR_OK);
+        auto work = [&](int i) {
+            apr_engine *e = engines[i];
+            try {
+                int r = check_engine(e);
+                if (!r) r = sweep_files_on(e, mine[i].data(), (int)mine[i].size(), pcm, nbytes, stride_bytes, trust, empty_class, probs, label, match, first.data());
+                rcs[i] = r;
+            } catch (const std::exception &ex) {
+                e->err = std::string("apr_sweep_files_multi: out of host memory: ") + ex.what();
+                rcs[i] = APR_ERR_NOMEM;
+            }
+        };
+        std::vector<std::thread> threads;
+        threads.reserve((size_t)n_engines);
+        for (int i = 1; i < n_engines; i++) {
+            try {
+                threads.emplace_back(work, i);
+            } catch (const std::exception &) {
+                work(i);                           // no thread to be had: this engine's share runs here, one after the other
+            }
+        }
+        work(0);
+        for (auto &t : threads) t.join();
+        for (int i = 0; i < n_engines; i++)
+            if (rcs[i]) {
+                if (i) e0->err = "engine " + std::to_string(i) + " (device " + std::to_string(engines[i]->device) + "): " + engines[i]->err;
+                return rcs[i];
+            }
+        return APR_OK;
+    } catch (const std::exception &ex) {
+        e0->err = std::string("apr_sweep_files_multi: ") + ex.what();
+        return APR_ERR_NOMEM;
+    }
 }
 
 int apr_profile_enable(apr_engine *e, int on)

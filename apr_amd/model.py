@@ -116,9 +116,10 @@ class Engine:
         self._lib = _capi.lib()
         h = C.c_void_p()
         mb = bytes(model_bytes) if model_bytes else None
-        rc = self._lib.apr_engine_create(mb, len(mb) if mb else 0, device, max_batch, C.byref(h))
+        errbuf = C.create_string_buffer(512)
+        rc = self._lib.apr_engine_create_ex(mb, len(mb) if mb else 0, device, max_batch, C.byref(h), errbuf, len(errbuf))
         if rc != 0:
-            raise AprError(rc, (self._lib.apr_last_error(None) or b"").decode())
+            raise AprError(rc, errbuf.value.decode(errors="replace"))
         self._h = h
         self.device = device
         self.num_classes = self._lib.apr_engine_num_classes(h)
@@ -219,6 +220,30 @@ class Engine:
                                             label.ctypes.data, match.ctypes.data, first))
         return dict(probs=probs, label=label, match=match, first_window=np.asarray(list(first), np.int64))
 
+    @staticmethod
+    def sweep_files_multi(engines, files, stride: int = BytesPerSecond, trust: float = 0.5, empty_class: int = -1):
+        """apr_sweep_files_multi: one engine per GPU of the node (the device list), recordings sharded by file
+        (file f -> engines[f % n]), rows written in file order -> dict as sweep_files."""
+        if not engines:
+            raise ValueError("sweep_files_multi needs at least one engine")
+        lib = engines[0]._lib
+        bufs = [_as_u8(f) for f in files]
+        n = len(bufs)
+        hs = (C.c_void_p * len(engines))(*[e._h.value for e in engines])
+        ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+        lens = (C.c_size_t * max(n, 1))(*[b.size for b in bufs])
+        first = (C.c_size_t * (n + 1))()
+        total = sum(windows_in(b.size, stride) for b in bufs)
+        nc = engines[0].num_classes
+        probs = np.empty((total, nc), np.float64)
+        label = np.empty(total, np.int32)
+        match = np.empty(total, np.uint8)
+        rc = lib.apr_sweep_files_multi(hs, len(engines), n, ptrs, lens, stride, trust, empty_class, probs.ctypes.data,
+                                       label.ctypes.data, match.ctypes.data, first)
+        if rc < 0:
+            raise AprError(rc, (lib.apr_last_error(engines[0]._h) or b"").decode())
+        return dict(probs=probs, label=label, match=match, first_window=np.asarray(list(first), np.int64))
+
     def upsample(self, pcm, up: int = 3, taps=None) -> np.ndarray:
         """apr_upsample: s16 PCM at rate r (host array) -> s16 PCM at rate ``up`` x r, on the GPU.  16 kHz sources
         become the 48 kHz this path scores; the reference delegates this to ffmpeg (src/ffmpeg/ffmpeg.go:76)."""
@@ -287,6 +312,7 @@ def windows_in(n_bytes: int, stride: int = BytesPerSecond) -> int:
 # ------------------------------------------------------------------------------------------
 _frontend: Dict[int, Engine] = {}
 _engines: Dict[tuple, Engine] = {}
+_hash_memo: Dict[int, tuple] = {}
 _default_device = 0
 
 
@@ -313,18 +339,51 @@ def Prepare(pcmData: bytes) -> np.ndarray:
     return out.reshape(1, 1, Nmels, SpectrogramFrames)
 
 
+def _model_key(raw: bytes, max_batch: int, device: int) -> tuple:
+    # by CONTENT, not by address: a model re-loaded after retraining has the same architecture and length and may
+    # land at the address the old bytes had
+    import hashlib
+    return (hashlib.sha256(raw).digest(), len(raw), max_batch, device)
+
+
 def engine_for(inferModel: OnnxModel, max_batch: int = 0) -> Engine:
-    """Device-resident engine cached by the identity of RawBytes: removes the per-call
-    backend build + UnmarshalBinary of model.go:190-196 without changing the API."""
-    key = (id(inferModel.RawBytes), len(inferModel.RawBytes), _default_device)
+    """Device-resident engine cached by the content of RawBytes (sha256), max_batch and device: removes the
+    per-call backend build + UnmarshalBinary of model.go:190-196 without changing the API.  The hash of the
+    94 MB is computed once per bytes object: the memo holds the object itself, so its address cannot be reused
+    while the entry exists (Unload drops it)."""
+    raw = inferModel.RawBytes
+    memo = _hash_memo.get(id(raw))
+    if memo is None or memo[0] is not raw:
+        _hash_memo[id(raw)] = memo = (raw, _model_key(raw, 0, 0)[0])
+    key = (memo[1], len(raw), max_batch, _default_device)
     e = _engines.get(key)
     if e is None:
         try:
-            e = Engine(inferModel.RawBytes, _default_device, max_batch)
+            e = Engine(raw, _default_device, max_batch)
         except AprError as err:
             raise Die(f"could not unmarshal ONNX model: {err}")
         _engines[key] = e
     return e
+
+
+def Unload(inferModel: Optional[OnnxModel] = None) -> int:
+    """Destroy the cached engines of one model (or of every model, and the front-end engines, when None): GPU memory
+    goes back at once.  No counterpart in the reference, whose Infer keeps nothing between calls.  Returns the count."""
+    n = 0
+    if inferModel is None:
+        for e in list(_engines.values()) + list(_frontend.values()):
+            e.close()
+            n += 1
+        _engines.clear()
+        _frontend.clear()
+        _hash_memo.clear()
+        return n
+    digest = _model_key(inferModel.RawBytes, 0, 0)[0]
+    for key in [k for k in _engines if k[0] == digest]:
+        _engines.pop(key).close()
+        n += 1
+    _hash_memo.pop(id(inferModel.RawBytes), None)
+    return n
 
 
 def softmax(logits) -> List[float]:
@@ -377,6 +436,19 @@ def synth_pcm(base_seed: int, file_index: int, n_seconds: int, second_offset: in
     if rc:
         raise AprError(rc, "apr_synth_pcm")
     return out
+
+
+def sweep_plan(file_bytes, n_devices: int, stride: int = BytesPerSecond):
+    """apr_sweep_plan (host only): (file_device [n], first_window [n+1], device_windows [n_devices])."""
+    n = len(file_bytes)
+    lens = (C.c_size_t * max(n, 1))(*[int(b) for b in file_bytes])
+    dev = np.zeros(max(n, 1), np.int32)
+    first = (C.c_size_t * (n + 1))()
+    per = (C.c_size_t * max(n_devices, 1))()
+    rc = _capi.lib().apr_sweep_plan(n, lens, stride, n_devices, dev.ctypes.data, first, per)
+    if rc:
+        raise AprError(rc, "apr_sweep_plan: bad argument")
+    return dev[:n], np.asarray(list(first), np.int64), np.asarray(list(per), np.int64)
 
 
 def model_info(model_bytes: bytes):

@@ -243,10 +243,12 @@ class MultiModelSweep:
         self.models = models
         self.trust = trust
 
-    def score_recording(self, pcm, stride: int = BYTES_PER_SECOND) -> Dict[str, dict]:
+    def score_recording(self, pcm, stride: int = BYTES_PER_SECOND, flavour: int = 0) -> Dict[str, dict]:
+        """flavour 0 (APR_FLAVOUR_GO): the daemon's Prepare (model.go:86); 1 (APR_FLAVOUR_LIBROSA): ai.inspect's
+        audio_to_spectrogram (ai/inspect.py:125 -> ai/model.py:184)."""
         b = np.ascontiguousarray(pcm).view(np.uint8).reshape(-1)
         n = windows_in(b.size, stride)
-        spec = self.frontend.prepare_batch(b, n, stride)
+        spec = self.frontend.prepare_batch(b, n, stride, flavour)
         out = {}
         for name, (eng, labels) in self.models.items():
             empty = labels.index("empty") if "empty" in labels else -1
@@ -255,8 +257,10 @@ class MultiModelSweep:
 
     def inspect_lines(self, file_name: str, pcm) -> List[str]:
         """What ``python -m ai.inspect -i <file>`` prints (ai/inspect.py:73-84): window-major,
-        model-minor, 1-based window index, 'empty' skipped, no threshold."""
-        res = self.score_recording(pcm)
+        model-minor, 1-based window index, 'empty' skipped, no threshold; spectrograms in the LIBROSA flavour, which
+        is what ai.inspect computes (ai/inspect.py:125).  One difference is kept: a ragged last slice (recording not
+        a whole number of seconds) is zero-padded to 2 s here, where ai.inspect hands librosa the short slice."""
+        res = self.score_recording(pcm, flavour=1)
         n = len(next(iter(res.values()))["label"]) if res else 0
         lines = []
         for k in range(n):

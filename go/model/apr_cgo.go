@@ -26,6 +26,7 @@ import (
 	"dtrack/ffmpeg"
 	"dtrack/log"
 
+	"crypto/sha256"
 	"runtime"
 	"sync"
 	"unsafe"
@@ -34,65 +35,133 @@ import (
 )
 
 // ---- engine cache -------------------------------------------------------------------------
-// One front-end engine for Prepare (single caller goroutine, daemon.go:123) and one engine
-// per model, keyed by the identity of RawBytes, each guarded by its own mutex (a handle is
-// safe for one caller at a time; the daemon runs one scanner goroutine per model).
+// One front-end engine for Prepare (single caller goroutine, daemon.go:123) and one engine per
+// (model content, max_batch, device), each guarded by its own mutex (a handle is safe for one
+// caller at a time; the daemon runs one scanner goroutine per model).  The key is the sha256 of
+// RawBytes, not its address: a model re-loaded after retraining has the same length and may be
+// handed the old address by the allocator.  The digest of a slice is memoised by (address, len)
+// together with the slice itself, so that address cannot be reused while the memo entry lives.
 type engine struct {
 	mu sync.Mutex
 	h  *C.apr_engine
 	nc int
 }
 
+type engineKey struct {
+	digest   [32]byte
+	maxBatch int
+	device   int
+}
+
+type digestMemo struct {
+	raw    []byte // keeps the backing array alive
+	digest [32]byte
+}
+
 var (
-	cacheMu  sync.Mutex
-	frontEnd *engine
-	engines  = map[uintptr]*engine{} // Infer: one clip per call
-	batchEngines = map[uintptr]*engine{} // ScoreBatch, SweepFiles
-	streamEngines = map[uintptr]*engine{} // StreamScorer (one engine per model; sized by the first NewStreamScorer)
+	cacheMu   sync.Mutex
+	frontEnds = map[int]*engine{}       // Prepare, Upsample3: one per device
+	engines   = map[engineKey]*engine{} // Infer (max_batch 1), ScoreBatch / SweepFiles (2048), StreamScorer (n streams)
+	digests   = map[uintptr]digestMemo{}
+	// Device is the GPU the package-level calls use (Prepare, Infer, ScoreBatch, SweepFiles, StreamScorer); set it
+	// before the first call, e.g. from a config key.  SweepFilesMulti takes its own device list.
+	Device = 0
 )
 
 func lastErr(h *C.apr_engine) string { return C.GoString(C.apr_last_error(h)) }
 
+// createEngine returns the handle or the library's reason.  apr_engine_create_ex copies the reason into a caller
+// buffer, so no second cgo call (possibly on another OS thread) is needed to fetch it.
+func createEngine(raw []byte, device, maxBatch int) (*C.apr_engine, string) {
+	var h *C.apr_engine
+	var errbuf [512]C.char
+	var p unsafe.Pointer
+	if len(raw) > 0 {
+		p = unsafe.Pointer(&raw[0])
+	}
+	rc := C.apr_engine_create_ex(p, C.size_t(len(raw)), C.int(device), C.int(maxBatch), &h, &errbuf[0], C.size_t(len(errbuf)))
+	if rc != 0 {
+		return nil, C.GoString(&errbuf[0])
+	}
+	return h, ""
+}
+
 func frontend() *engine {
 	cacheMu.Lock()
 	defer cacheMu.Unlock()
-	if frontEnd == nil {
-		var h *C.apr_engine
-		if rc := C.apr_engine_create(nil, 0, 0, 64, &h); rc != 0 {
-			log.Die("GPU front end unavailable: %s", lastErr(nil))
+	fe := frontEnds[Device]
+	if fe == nil {
+		h, why := createEngine(nil, Device, 64)
+		if h == nil {
+			log.Die("GPU front end unavailable: %s", why)
 		}
-		frontEnd = &engine{h: h}
+		fe = &engine{h: h}
+		frontEnds[Device] = fe
 	}
-	return frontEnd
+	return fe
 }
 
-func engineFor(m OnnxModel) *engine { return cachedEngine(m, 1, engines) }
+func engineFor(m OnnxModel) *engine { return cachedEngine(m, 1, Device) }
 
 // batchEngineFor: the engine of ScoreBatch / SweepFiles (2048 windows per GPU pass).
-func batchEngineFor(m OnnxModel) *engine { return cachedEngine(m, 2048, batchEngines) }
+func batchEngineFor(m OnnxModel) *engine { return cachedEngine(m, 2048, Device) }
+
+func digestOf(raw []byte) [32]byte { // cacheMu held
+	addr := uintptr(unsafe.Pointer(&raw[0]))
+	if d, ok := digests[addr]; ok && len(d.raw) == len(raw) {
+		return d.digest
+	}
+	d := digestMemo{raw: raw, digest: sha256.Sum256(raw)}
+	digests[addr] = d
+	return d.digest
+}
 
 // Infer scores one clip per call (daemon.go:132-136), so its engine is created with max_batch 1:
 // a few MB of activations instead of 8 GB, and the library runs the late, tiny-grid layers split
 // along K and replays the call as a captured hipGraph (p50 0.30 ms per clip instead of 1.7 ms).
-func cachedEngine(m OnnxModel, maxBatch int, cache map[uintptr]*engine) *engine {
+func cachedEngine(m OnnxModel, maxBatch, device int) *engine {
 	if len(m.RawBytes) == 0 {
 		log.Die("could not unmarshal ONNX model: empty")
 	}
-	key := uintptr(unsafe.Pointer(&m.RawBytes[0]))
 	cacheMu.Lock()
 	defer cacheMu.Unlock()
-	if e, ok := cache[key]; ok {
+	key := engineKey{digestOf(m.RawBytes), maxBatch, device}
+	if e, ok := engines[key]; ok {
 		return e
 	}
-	var h *C.apr_engine
 	// replaces gorgonnx.NewGraph() + UnmarshalBinary on every call (model.go:190-196)
-	rc := C.apr_engine_create(unsafe.Pointer(&m.RawBytes[0]), C.size_t(len(m.RawBytes)), 0, C.int(maxBatch), &h)
-	if rc != 0 {
-		log.Die("could not unmarshal ONNX model: %s", lastErr(nil))
+	h, why := createEngine(m.RawBytes, device, maxBatch)
+	if h == nil {
+		log.Die("could not unmarshal ONNX model: %s", why)
 	}
 	e := &engine{h: h, nc: int(C.apr_engine_num_classes(h))}
-	cache[key] = e
+	engines[key] = e
 	return e
+}
+
+// Unload destroys every cached engine of this model (all batch sizes, all devices) and forgets its digest: the GPU
+// memory goes back at once.  No counterpart in the reference, whose Infer keeps nothing between calls.  Callers must
+// not be inside Infer / ScoreBatch / Tick on that model.
+func Unload(m OnnxModel) int {
+	if len(m.RawBytes) == 0 {
+		return 0
+	}
+	cacheMu.Lock()
+	defer cacheMu.Unlock()
+	d := digestOf(m.RawBytes)
+	n := 0
+	for k, e := range engines {
+		if k.digest == d {
+			e.mu.Lock()
+			C.apr_engine_destroy(e.h)
+			e.h = nil
+			e.mu.Unlock()
+			delete(engines, k)
+			n++
+		}
+	}
+	delete(digests, uintptr(unsafe.Pointer(&m.RawBytes[0])))
+	return n
 }
 
 // Prepare raw audio bytes and convert them to a ready-to-infer tensor (model.go:86-184).
@@ -194,7 +263,7 @@ type StreamScorer struct {
 }
 
 func NewStreamScorer(inferModel OnnxModel, nStreams int) *StreamScorer {
-	e := cachedEngine(inferModel, nStreams, streamEngines)
+	e := cachedEngine(inferModel, nStreams, Device)
 	empty := -1
 	for i, l := range inferModel.Labels {
 		if l == "empty" {
@@ -297,6 +366,75 @@ func SweepFiles(inferModel OnnxModel, files [][]byte, trust float64) (probs [][]
 	match = make([]bool, total)
 	for k := 0; k < total; k++ {
 		probs[k] = flat[k*e.nc : (k+1)*e.nc]
+		match[k] = m[k] != 0
+	}
+	for f := range first {
+		first[f] = int(cfirst[f])
+	}
+	return
+}
+
+// SweepFilesMulti is SweepFiles over a device list from ONE process (apr_sweep_files_multi): recordings are sharded
+// by file, file f -> devices[f % len(devices)] (SURVEY 8(e); the loop being sharded is ai/inspect.py:20-70,73-112 /
+// daemon.go:87-141), one host thread per device inside the library, rows returned in FILE order.  The results are
+// host memory, so every GPU's rows cross its own PCIe link once; no device-side gather is involved.
+func SweepFilesMulti(inferModel OnnxModel, devices []int, files [][]byte, trust float64) (probs [][]float64, label []int32, match []bool, first []int) {
+	nf := len(files)
+	first = make([]int, nf+1)
+	if nf == 0 || len(devices) == 0 {
+		return
+	}
+	es := make([]*engine, len(devices))
+	hs := (*[1 << 16]*C.apr_engine)(C.malloc(C.size_t(len(devices)) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:len(devices):len(devices)]
+	defer C.free(unsafe.Pointer(&hs[0]))
+	for i, d := range devices {
+		es[i] = cachedEngine(inferModel, 2048, d) // the same device twice would list one handle twice: refused by the library
+		hs[i] = es[i].h
+	}
+	empty := -1
+	for i, l := range inferModel.Labels {
+		if l == "empty" {
+			empty = i
+		}
+	}
+	ptrs := (*[1 << 28]*C.uint8_t)(C.malloc(C.size_t(nf) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:nf:nf]
+	lens := (*[1 << 28]C.size_t)(C.malloc(C.size_t(nf) * C.size_t(unsafe.Sizeof(C.size_t(0)))))[:nf:nf]
+	cfirst := (*[1 << 28]C.size_t)(C.malloc(C.size_t(nf+1) * C.size_t(unsafe.Sizeof(C.size_t(0)))))[: nf+1 : nf+1]
+	defer C.free(unsafe.Pointer(&ptrs[0]))
+	defer C.free(unsafe.Pointer(&lens[0]))
+	defer C.free(unsafe.Pointer(&cfirst[0]))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	total := 0
+	for f, b := range files {
+		lens[f] = C.size_t(len(b))
+		ptrs[f] = nil
+		if len(b) > 0 {
+			pin.Pin(&b[0])
+			ptrs[f] = (*C.uint8_t)(unsafe.Pointer(&b[0]))
+		}
+		total += int(C.apr_windows_in(C.size_t(len(b)), C.size_t(ffmpeg.BytesPerSecond)))
+	}
+	nc := es[0].nc
+	flat := make([]float64, total*nc+1)
+	label = make([]int32, total+1)
+	m := make([]uint8, total+1)
+	for _, e := range es {
+		e.mu.Lock()
+	}
+	rc := C.apr_sweep_files_multi(&hs[0], C.int(len(devices)), C.int(nf), &ptrs[0], &lens[0], C.size_t(ffmpeg.BytesPerSecond), C.double(trust),
+		C.int(empty), (*C.double)(unsafe.Pointer(&flat[0])), (*C.int32_t)(unsafe.Pointer(&label[0])), (*C.uint8_t)(unsafe.Pointer(&m[0])), &cfirst[0])
+	for _, e := range es {
+		e.mu.Unlock()
+	}
+	if rc != 0 {
+		log.Die("Inference failed: %v", lastErr(es[0].h))
+	}
+	label = label[:total]
+	probs = make([][]float64, total)
+	match = make([]bool, total)
+	for k := 0; k < total; k++ {
+		probs[k] = flat[k*nc : (k+1)*nc]
 		match[k] = m[k] != 0
 	}
 	for f := range first {

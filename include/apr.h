@@ -79,6 +79,11 @@ const char *apr_version(void);
  * src/model/model.go:190-196: parsing and upload happen once, here.
  */
 int apr_engine_create(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out);
+/* Same, and on failure the reason is also copied into errbuf (NUL-terminated, truncated to errbuf_len): the text the
+ * Go shim hands to log.Die("could not unmarshal ONNX model: %s") (src/model/model.go:194-196).  apr_last_error(NULL)
+ * keeps the reason per OS thread, which a goroutine may have left by its next cgo call; this form does not depend on it. */
+int apr_engine_create_ex(const void *model_bytes, size_t n, int device_id, int max_batch, apr_engine **out, char *errbuf,
+                         size_t errbuf_len);
 void apr_engine_destroy(apr_engine *e);
 
 /*
@@ -222,11 +227,30 @@ size_t apr_windows_in(size_t nbytes, size_t stride_bytes);
  * row.  Files are packed back to back into full GPU passes (a long file spans several passes, short
  * files share one), through two pinned staging buffers: the host->device copy of pass p+1 runs on a
  * copy stream while pass p computes.  probs/label/match as in apr_score; host pointers; synchronous.
- * The multi-GPU form is one process per GPU, each sweeping its own files (apr_amd/sweep.py:
- * shard_files + gather_scores over RCCL).
+ * A call that fails while allocating its staging is resumed by the next call (nothing leaks); the stride may change
+ * between calls (the staging is re-sized).
  */
 int apr_sweep_files(apr_engine *e, int n_files, const uint8_t *const *pcm, const size_t *nbytes, size_t stride_bytes,
                     double trust, int empty_class, double *probs, int32_t *label, uint8_t *match, size_t *first_window);
+
+/*
+ * The same sweep over the GPUs of one node from ONE process: the directory loop of ai/inspect.py:20-70,73-112 /
+ * the scanner fan-out of src/daemon/daemon.go:87-141 sharded BY FILE.  `engines` lists one engine per device to use
+ * (created by the caller with apr_engine_create on the device ids it wants -- the device list of the sweep -- all from
+ * the same model bytes; distinct handles); file f goes to engines[f % n_engines] (round-robin by index, so no window
+ * crosses a shard).  One host thread per engine stages that engine's files through its own pinned buffers; every row
+ * lands directly in the caller's host arrays at first_window[f] + k, i.e. in FILE order whatever device scored it.
+ * Because the destination is host memory, each GPU's rows cross its own PCIe link once and there is no device-side
+ * gather (that is for device-resident results of one process per GPU: apr_amd/sweep.py gather_scores over RCCL).
+ * n_engines == 1 is bit-identical to apr_sweep_files.  On failure the reason is in apr_last_error(engines[0]).
+ * apr_sweep_plan is the host-only plan (no GPU): file -> index into the device list, first row of every file
+ * (n_files + 1 entries), windows per device (n_devices entries); any output may be NULL.
+ */
+int apr_sweep_plan(int n_files, const size_t *nbytes, size_t stride_bytes, int n_devices, int32_t *file_device,
+                   size_t *first_window, size_t *device_windows);
+int apr_sweep_files_multi(apr_engine *const *engines, int n_engines, int n_files, const uint8_t *const *pcm,
+                          const size_t *nbytes, size_t stride_bytes, double trust, int empty_class, double *probs,
+                          int32_t *label, uint8_t *match, size_t *first_window);
 
 /*
  * Offset of the PCM payload in a RIFF/WAVE byte stream (0 if `buf` is not RIFF or holds no data

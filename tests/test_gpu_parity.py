@@ -155,6 +155,9 @@ def test_score_matches_oracle_labels(eng, he_weights):
     assert np.array_equal(got["label"][decided], want["label"][decided])
     near = np.abs(want["probs"].max(axis=1) - 0.5) < 1e-3
     assert np.array_equal(got["match"][decided & ~near], want["match"][decided & ~near])
+    # on ALL windows, near-ties included: at most the near-ties may differ
+    assert int((got["label"] != want["label"]).sum()) <= int((~decided).sum())
+    assert int((got["match"] != want["match"]).sum()) <= int((~decided | near).sum())
 
 
 def test_score_chunking_is_invisible(he_weights):
@@ -407,13 +410,18 @@ def test_full_size_sweep_properties(he_weights):
     va = plan.valid[:h - 1]
     assert np.array_equal(probs[:h - 1][va], probs[h:2 * h - 1][va]) and np.array_equal(label[:h - 1][va], label[h:2 * h - 1][va])
     # oracle on a sample spread over the sweep
-    ks = [k for k in np.linspace(0, n - 1, 24).astype(int) if plan.valid[k]]
+    # (label / match mismatches are counted on ALL sampled windows; one is tolerated only on a near-tie: top-2 logit
+    # margin within 2 x the logit tolerance, or confidence within 1e-3 of the trust threshold)
+    ks = [k for k in np.linspace(0, n - 1, 48).astype(int) if plan.valid[k]]
+    mismatches = 0
     for k in ks:
         ref = oracle.score(flat, C, pcm[k * 48000:(k + 2) * 48000], 1, trust=trust, empty_class=empty)
         assert np.abs(ref["probs"][0] - probs[k]).max() <= 1e-4
         srt = np.sort(ref["logits"][0])
-        if srt[-1] - srt[-2] > 4e-4:
-            assert ref["label"][0] == label[k] and ref["match"][0] == match[k]
+        if ref["label"][0] != label[k] or ref["match"][0] != match[k]:
+            mismatches += 1
+            assert srt[-1] - srt[-2] <= 4e-4 or abs(ref["probs"][0].max() - trust) < 1e-3, k
+    assert mismatches <= 1, mismatches
     # timestamps as ai/inspect.py prints them: window k of file f is second k+1
     lines = sweep.format_matches("m", LABELS, {f: f"rec{f}.mkv" for f in range(n_files)}, plan, label, match)
     assert len(lines) == int((match.astype(bool) & plan.valid).sum())

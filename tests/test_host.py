@@ -195,3 +195,113 @@ def test_resample_taps_match_oracle_definition():
     for bad in ((0, 32, 0.97, 9.0), (3, 31, 0.97, 9.0), (3, 0, 0.97, 9.0), (3, 512, 0.97, 9.0), (3, 32, 0.0, 9.0), (3, 32, 1.5, 9.0), (3, 32, 0.97, -1.0)):
         with pytest.raises(_capi.AprError):
             sweep.resample_taps(*bad)
+
+
+def _tiny_onnx(gemm_dims, gemm_floats, trans_b=1, conv_dims=(32, 1, 3, 3)):
+    """Conv -> Relu -> GlobalMaxPool -> Flatten -> Gemm with hand-set (possibly lying) dims."""
+    def tensor(name, dims, n_floats):
+        t = b"".join(W._vi(1, d) for d in dims) + W._vi(2, 1)
+        return t + W._s(8, name) + W._ld(9, np.zeros(n_floats, "<f4").tobytes())
+    conv_attrs = [W._attr_ints("pads", [1, 1, 1, 1]), W._attr_ints("strides", [1, 1])]
+    nodes = [W._node("Conv", ["input", "w", "b"], ["c"], conv_attrs), W._node("Relu", ["c"], ["r"]),
+             W._node("GlobalMaxPool", ["r"], ["p"]), W._node("Flatten", ["p"], ["f"]),
+             W._node("Gemm", ["f", "fw"], ["output"], [W._attr_int("transB", trans_b)])]
+    n_conv = int(np.prod([max(d, 0) for d in conv_dims]))
+    inits = [tensor("w", conv_dims, min(n_conv, 1 << 16)), tensor("b", [max(conv_dims[0], 0)], min(max(conv_dims[0], 0), 64)),
+             tensor("fw", gemm_dims, gemm_floats)]
+    graph = b"".join(W._ld(1, n) for n in nodes) + b"".join(W._ld(5, t) for t in inits)
+    return W._vi(1, 8) + W._ld(7, graph)
+
+
+def test_gemm_and_conv_dims_are_checked_against_payload():
+    # ADVICE r1: dims that lie about the payload must be a model error, not an over-read / bad_alloc
+    assert model.model_info(_tiny_onnx([4, 32], 4 * 32)) == (4, 1)            # the honest tiny graph parses
+    for dims, n, tb, why in (([4, 32], 10, 1, "size does not match"), ([32, 4], 10, 0, "size does not match"),
+                             ([1 << 31, 1 << 31], 16, 1, "out of range"), ([1 << 40, 1], 16, 0, "out of range"),
+                             ([0, 32], 0, 1, "out of range"), ([65, 32], 65 * 32, 1, "out of range"),
+                             ([4, 1 << 20], 16, 1, "out of range")):
+        with pytest.raises(_capi.AprError) as ei:
+            model.model_info(_tiny_onnx(dims, n, tb))
+        assert ei.value.code == _capi.ERR_MODEL and why in str(ei.value), (dims, str(ei.value))
+    for conv in ((0, 1, 3, 3), (32, 0, 3, 3), (1 << 33, 1, 3, 3)):
+        with pytest.raises(_capi.AprError) as ei:
+            model.model_info(_tiny_onnx([4, 32], 128, conv_dims=conv))
+        assert ei.value.code == _capi.ERR_MODEL and "width out of range" in str(ei.value)
+    # APRW blob claiming more classes than the library supports
+    blob = bytearray(W.pack_blob(W.random_init(4, 0, "he"), 4))
+    blob[8:12] = (10 ** 6).to_bytes(4, "little")
+    with pytest.raises(_capi.AprError):
+        model.model_info(bytes(blob))
+
+
+def test_sweep_plan_round_robin_by_file():
+    # SURVEY 8(e): by file, round-robin by index; rows of the result are in file order whatever device scored them
+    secs = [5.0, 1.0, 0.5, 3.3, 40.0, 0.0, 2.0, 2.01, 7.0, 600.0]
+    nbytes = [int(s * 48000) * 2 for s in secs]
+    counts = [sweep.windows_in(b) for b in nbytes]
+    for nd in (1, 2, 4, 8):
+        dev, first, per = model.sweep_plan(nbytes, nd)
+        assert dev.tolist() == [f % nd for f in range(len(secs))]
+        assert first.tolist() == np.concatenate([[0], np.cumsum(counts)]).tolist()
+        assert per.tolist() == [sum(c for f, c in enumerate(counts) if f % nd == d) for d in range(nd)]
+        assert per.sum() == sum(counts)
+    # BASELINE config 3: 6000 x 600 s over 8 devices = 750 files and 449 250 windows each
+    dev, first, per = model.sweep_plan([600 * 96000] * 6000, 8)
+    assert per.tolist() == [750 * 599] * 8 and first[-1] == 3594000
+    dev, first, per = model.sweep_plan([], 3)
+    assert first.tolist() == [0] and per.tolist() == [0, 0, 0]
+    with pytest.raises(_capi.AprError):
+        model.sweep_plan([96000], 0)
+
+
+def test_header_is_plain_c99_and_callable_from_c(tmp_path):
+    # cgo consumes include/apr.h as C: compile it as C99 and drive the host-only entry points from a C program
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    inc = os.path.join(REPO, "include")
+    subprocess.check_call([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "apr.h")])
+    src = tmp_path / "use_apr.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "apr.h"
+int main(void) {
+    int nc = -1, nl = -1;
+    size_t lens[5] = {5 * 96000, 96000, 0, 3 * 96000 + 10, 600 * 96000}, first[6], per[2];
+    int32_t dev[5];
+    int32_t label[150];
+    uint8_t match[150], hits[3 * 4];
+    if (apr_model_info("garbage!", 8, &nc, &nl) != APR_ERR_MODEL) return 1;
+    if (strlen(apr_last_error(NULL)) == 0) return 2;
+    if (apr_windows_in(600 * 96000, 96000) != 599 || apr_windows_in(96000, 96000) != 0) return 3;
+    if (apr_sweep_plan(5, lens, 96000, 2, dev, first, per) != APR_OK) return 4;
+    if (first[5] != 4 + 0 + 0 + 3 + 599 || per[0] != 4 + 0 + 599 || per[1] != 3 || dev[3] != 1) return 5;
+    memset(match, 0, sizeof match);
+    for (int k = 0; k < 150; k++) label[k] = 2;
+    label[61] = 3; match[61] = 1;
+    if (apr_bucket_hits(label, match, 150, 4, 60, hits) != APR_OK || hits[1 * 4 + 3] != 1 || hits[0] != 0) return 6;
+    printf("%s\n", apr_version());
+    return 0;
+}
+''')
+    exe = tmp_path / "use_apr"
+    libdir = os.path.join(REPO, "apr_amd")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lapr_amd",
+                           "-Wl,-rpath," + libdir])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert "gfx950" in r.stdout
+
+
+def test_create_error_text_comes_back_through_the_out_parameter():
+    import ctypes as C
+    L = _capi.lib()
+    h = C.c_void_p()
+    buf = C.create_string_buffer(256)
+    rc = L.apr_engine_create_ex(b"not a model", 11, 0, 8, C.byref(h), buf, len(buf))
+    assert rc < 0 and not h.value and len(buf.value) > 0          # "no HIP device available" here, the parser's text on a GPU box
+    small = C.create_string_buffer(8)
+    assert L.apr_engine_create_ex(b"not a model", 11, 0, 8, C.byref(h), small, len(small)) < 0 and len(small.value) == 7

@@ -79,9 +79,68 @@ def test_KA4_bin_centred_sine():
     assert int(np.argmax(mel[:, 10])) in covering
 
 
+def _mel_lens_from_dsp_go():
+    """The go mel lens a second time, in numpy, straight from src/model/dsp.go:31-80 and 158-165 -- written
+    without looking at oracle/apr_oracle.c, so a misreading there would show as a difference."""
+    nbins = 2048 // 2 + 1
+    hz_to_mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)                 # dsp.go:158-160
+    mel_to_hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)               # dsp.go:163-165
+    lo, hi = hz_to_mel(0.0), hz_to_mel(24000.0)
+    step = (hi - lo) / (128 + 1)
+    pts_hz = np.array([mel_to_hz(lo + i * step) for i in range(130)])
+    bins = np.floor((2048 + 1) * pts_hz / 48000.0).astype(int)              # dsp.go:48
+    w = np.zeros((128, nbins))
+    for i in range(128):
+        start, center, end = bins[i], bins[i + 1], bins[i + 2]
+        for f in range(start, center):                                       # rising edge: starts at weight 0
+            if f >= nbins:
+                break
+            w[i, f] = (f - start) / (center - start)
+        for f in range(center, end):                                         # falling edge: centre bin has weight 1
+            if f >= nbins:
+                break
+            w[i, f] = (end - f) / (end - center)
+    return w, bins
+
+
+def test_mel_lens_equals_an_independent_numpy_restatement_of_dsp_go():
+    w_np, bins_np = _mel_lens_from_dsp_go()
+    w, bounds, pts = oracle.mel_lens()
+    assert np.array_equal(pts, bins_np)
+    assert np.array_equal(bounds[:, 0], bins_np[:128]) and np.array_equal(bounds[:, 1], bins_np[2:])
+    assert np.array_equal(w, w_np)                                           # f64 quotients of small integers: bit-equal
+    assert int((w_np != 0).sum()) == 1892
+
+
+def test_window_and_frame_grids_against_scipy():
+    # librosa flavour: librosa.stft's default window is scipy.signal.get_window('hann', n_fft, fftbins=True) (periodic);
+    # go flavour: go-dsp window.Hann(L) is the symmetric form (divisor L-1) = get_window(..., fftbins=False)
+    from scipy.signal import get_window
+    sym, per = oracle.hann()
+    np.testing.assert_allclose(per, get_window("hann", 2048, fftbins=True), rtol=0, atol=1e-15)
+    np.testing.assert_allclose(sym, get_window("hann", 2048, fftbins=False), rtol=0, atol=1e-15)
+    assert sym[0] == 0.0 and abs(sym[-1]) < 1e-15 and per[0] == 0.0 and per[-1] > 0.0
+    # frame grids: go = 184 uncentred frames (model.go:106), librosa = 1 + 96000 // 512 = 188 frames centred on 512 t
+    assert (96000 - 2048) // 512 + 1 == 184 and 1 + 96000 // 512 == 188
+    # centred, zero-padded framing (librosa >= 0.10 pad_mode="constant"): an impulse at sample 512 t sits at the centre of
+    # frame t, where the periodic Hann is exactly 1 -> a flat spectrum of power 1 in that frame and in no frame further than
+    # 2 hops away
+    x = np.zeros(96000, np.float32)
+    x[512 * 50] = 1.0
+    ref = np.pad(x.astype(np.float64), 1024)
+    fr = np.stack([ref[512 * t:512 * t + 2048] * per for t in range(188)])
+    P = np.abs(np.fft.rfft(fr, axis=1)) ** 2                                # [188][1025]
+    assert np.allclose(P[50], 1.0) and P[47].max() == 0.0 and P[53].max() == 0.0
+    M = oracle.librosa_mel_basis().astype(np.float64) @ P.T                 # [128][188]
+    db = 10 * np.log10(np.maximum(M, 1e-10)) - 10 * np.log10(max(M.max(), 1e-10))
+    want = ((np.clip(np.maximum(db, db.max() - 80), -80, 0) + 80) / 80).astype(np.float32)
+    got = oracle.prepare_librosa(x)
+    assert got.shape == (128, 188) and np.abs(got - want).max() < 2e-6
+
+
 def test_numpy_cross_check_of_the_go_front_end(clips, ramp_pcm):
-    # independent formulation (numpy FFT, dense lens matmul); not a pin of the reference itself
-    w, _, _ = oracle.mel_lens()
+    # independent formulation (numpy FFT, dense matmul with the numpy lens above); not a pin of the reference itself
+    w, _ = _mel_lens_from_dsp_go()
     hann = 0.5 * (1 - np.cos(2 * np.pi * np.arange(2048) / 2047))
     for pcm in (clips["test_bigdog"], clips["test_empty"], ramp_pcm):
         x = (pcm.view("<i2").astype(np.float32) / np.float32(32768)).astype(np.float64)
