@@ -278,9 +278,16 @@ int build_frontend(apr_engine *e)
         const double a = 2.0 * M_PI * (double)i / (double)kNfft;
         tw[i] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
     }
-    float2 *d_tw = nullptr;
+    // the same values in the order the lanes of passes 2 and 3 read them (frontend.hip.h, FrontendTables::tw23)
+    std::vector<float2> tw23(1024);
+    for (int t = 0; t < 16; t++)
+        for (int k = 0; k < 16; k++) tw23[16 * t + k] = tw[8 * k * t];
+    for (int t = 1; t <= 3; t++)
+        for (int j = 0; j < 256; j++) tw23[256 * t + j] = tw[2 * j * t];
+    float2 *d_tw = nullptr, *d_tw23 = nullptr;
     int rc = dev_upload(e, &d_tw, tw);
     if (rc) return rc;
+    if ((rc = dev_upload(e, &d_tw23, tw23))) return rc;
     for (int fl = 0; fl < 2; fl++) {
         std::vector<float> win(kNfft);
         for (int n = 0; n < kNfft; n++) {
@@ -290,14 +297,29 @@ int build_frontend(apr_engine *e)
         }
         Csr c = fl == APR_FLAVOUR_GO ? mel_lens_go() : mel_lens_librosa();
         if ((int)c.w.size() > kMaxNnz) { e->err = "mel lens exceeds CSR capacity"; return APR_ERR_INVALID; }
-        float *d_win = nullptr, *d_w = nullptr;
-        int *d_s = nullptr, *d_l = nullptr, *d_o = nullptr;
+        // the same lens with every band widened to whole quads of bins that start at a multiple of 4 (+0 weights outside
+        // the band): the kernel reads four bins per LDS access on both operands
+        std::vector<int> s4(kNmels), l4(kNmels), o4(kNmels);
+        std::vector<float> wp;
+        for (int m = 0; m < kNmels; m++) {
+            const int st = c.start[m] & ~3, en = c.start[m] + c.len[m];
+            s4[m] = st;
+            l4[m] = c.len[m] > 0 ? (en - st + 3) / 4 : 0;
+            o4[m] = (int)wp.size();
+            for (int k = st; k < st + 4 * l4[m]; k++) wp.push_back(k >= c.start[m] && k < en ? c.w[(size_t)c.off[m] + (k - c.start[m])] : 0.0f);
+        }
+        if ((int)wp.size() > kMaxNnzPad) { e->err = "padded mel lens exceeds its LDS capacity"; return APR_ERR_INVALID; }
+        float *d_win = nullptr, *d_w = nullptr, *d_wp = nullptr;
+        int *d_s = nullptr, *d_l = nullptr, *d_o = nullptr, *d_s4 = nullptr, *d_l4 = nullptr, *d_o4 = nullptr;
         if ((rc = dev_upload(e, &d_win, win)) || (rc = dev_upload(e, &d_w, c.w)) || (rc = dev_upload(e, &d_s, c.start)) ||
-            (rc = dev_upload(e, &d_l, c.len)) || (rc = dev_upload(e, &d_o, c.off)))
+            (rc = dev_upload(e, &d_l, c.len)) || (rc = dev_upload(e, &d_o, c.off)) || (rc = dev_upload(e, &d_wp, wp)) ||
+            (rc = dev_upload(e, &d_s4, s4)) || (rc = dev_upload(e, &d_l4, l4)) || (rc = dev_upload(e, &d_o4, o4)))
             return rc;
         FrontendTables &T = e->tab[fl];
-        T.window = d_win; T.tw = d_tw; T.mel_start = d_s; T.mel_len = d_l; T.mel_off = d_o; T.mel_w = d_w;
+        T.window = d_win; T.tw = d_tw; T.tw23 = d_tw23; T.mel_start = d_s; T.mel_len = d_l; T.mel_off = d_o; T.mel_w = d_w;
+        T.mel_start4 = d_s4; T.mel_len4 = d_l4; T.mel_off4 = d_o4; T.mel_wp = d_wp;
         T.nnz = (int)c.w.size();
+        T.nnz_pad = (int)wp.size();
         T.n_frames = fl == APR_FLAVOUR_GO ? (APR_SAMPLE_SIZE / 2 - kNfft) / kHop + 1 : 1 + (APR_SAMPLE_SIZE / 2) / kHop;
         T.frame_origin = fl == APR_FLAVOUR_GO ? 0 : -(kNfft / 2);
         T.librosa = fl;
@@ -521,14 +543,14 @@ int run_frontend(apr_engine *e, int flavour, const uint8_t *d_pcm, size_t total_
 {
     if (!melT) melT = e->d_melT;
     const FrontendTables &T = e->tab[flavour];
-    const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
-    // a handful of windows (live clips): db_norm gets one block per 32-frame column chunk instead of one per
-    // window, so its latency is a sixth; the arithmetic per element is the same code
+    // a handful of windows (live clips): one frame per wave and, in db_norm, one block per 32-frame column chunk instead
+    // of one per window, so the latency is a fraction; the arithmetic per element is the same code
     const bool few = n_windows <= 8;
+    const int groups = (T.n_frames + kFramesPerBlock - 1) / kFramesPerBlock;
     {
         ProfScope ps(e, timed ? 0 : -1, (double)n_windows * T.n_frames * 5.0 * kNfft * 11.0 + 2.0 * T.nnz * T.n_frames * n_windows,
                      (double)n_windows * (std::min<size_t>(stride, APR_SAMPLE_SIZE) + (double)T.n_frames * kNmels * 4));
-        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(256), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, melT);
+        hipLaunchKernelGGL(stft_mel_kernel, dim3(n_windows * groups), dim3(64 * kFramesPerBlock), 0, e->stream, d_pcm, total_bytes, stride, n_windows, T, melT);
     }
     {
         ProfScope ps(e, timed ? 1 : -1, 0.0, (double)n_windows * ((double)T.n_frames * kNmels * 4 + APR_SPEC_ELEMS * 4));

@@ -23,18 +23,28 @@ constexpr int kHop = 512;
 constexpr int kNmels = 128;
 constexpr int kSpecFrames = 188;
 constexpr int kSampleBytes = 192000;
-constexpr int kFramesPerBlock = 4;    // one frame per wave: 90 VGPRs, 3 workgroups per CU (LDS-bound).  Four frames per wave
-                                      // let hipcc keep window + twiddles in registers (246 VGPRs, 2 waves/SIMD) and ran 24 % slower.
+#ifndef APR_FE_FPB
+#define APR_FE_FPB 8
+#endif
+constexpr int kFramesPerBlock = APR_FE_FPB;    // frames per workgroup = its waves (one frame per wave): the tables a workgroup stages in LDS
+                                      // serve eight frames; 56 KB of LDS = two workgroups, 16 waves per CU
 constexpr int kMaxNnz = 2304;         // CSR capacity (go lens: 1892, librosa: ~2.1k)
+constexpr int kMaxNnzPad = 2688;      // the same with every band widened to whole quads of bins starting at a multiple of 4
 
 struct FrontendTables {
     const float *window;     // [2048] analysis window
     const float2 *tw;        // [2048] W_2048^i = (cos(2*pi*i/2048), -sin(2*pi*i/2048))
+    const float2 *tw23;      // [256 + 768] the twiddles of passes 2 and 3 in the order the lanes read them:
+                             // [16 t + k] = W_256^(k t) (k, t < 16), then [256 (t - 1) + j] = W_1024^(j t) (t = 1..3, j < 256)
     const int *mel_start;    // [128] first bin of each band
     const int *mel_len;      // [128] bins in each band
     const int *mel_off;      // [128] offset of each band in mel_w
     const float *mel_w;      // [nnz] band weights, bin-ascending per band
-    int nnz;
+    const int *mel_start4;   // [128] first bin of the band's first quad (mel_start rounded down to a multiple of 4)
+    const int *mel_len4;     // [128] quads of bins the band touches
+    const int *mel_off4;     // [128] offset of the band's padded weights in mel_wp (a multiple of 4)
+    const float *mel_wp;     // [nnz_pad] weights of whole quads: +0 outside the band
+    int nnz, nnz_pad;
     int n_frames;            // 184 (go) or 188 (librosa)
     int frame_origin;        // first frame starts at this sample: 0 (go) or -1024 (librosa centre pad)
     int librosa;             // dB stage flavour
@@ -95,48 +105,67 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-constexpr int kLdsWave = 1104;   // padded complex-plane length (pidx(1024) = 1088 fits)
+constexpr int kLdsPlane = 1104;   // padded real plane of one wave (pidx(1024) = 1088 fits; the power spectrum needs 1032)
 
-__global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict__ pcm, size_t total_bytes,
-                                                       size_t stride_bytes, int n_windows, FrontendTables T,
-                                                       float *__restrict__ melT /*[n_windows][188][128]*/)
+// Exchange of one pass through the wave's single real plane: every lane writes its 16 values at WI(t), the wave reads
+// them back at RI(t) -- first the real parts, then the imaginary parts (half the LDS of two planes: four workgroups
+// per CU instead of three).  v[SLOT(t)] is written, v[t] is read.
+#define APR_FE_EXCHANGE(WI, SLOT, RI)                                              \
+    {                                                                              \
+        float xr_[16];                                                             \
+        _Pragma("unroll") for (int t = 0; t < 16; t++) pl[WI] = v[SLOT].x;         \
+        wave_lds_sync();                                                           \
+        _Pragma("unroll") for (int t = 0; t < 16; t++) xr_[t] = pl[RI];            \
+        wave_lds_sync();                                                           \
+        _Pragma("unroll") for (int t = 0; t < 16; t++) pl[WI] = v[SLOT].y;         \
+        wave_lds_sync();                                                           \
+        _Pragma("unroll") for (int t = 0; t < 16; t++) v[t] = make_float2(xr_[t], pl[RI]); \
+        wave_lds_sync();                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                         \
+    }
+
+__global__ __launch_bounds__(64 * kFramesPerBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_mel_kernel(
+    const uint8_t *__restrict__ pcm, size_t total_bytes, size_t stride_bytes, int n_windows, FrontendTables T,
+    float *__restrict__ melT /*[n_windows][188][128]*/)
 {
-    __shared__ float s_re[4][kLdsWave];
-    __shared__ float s_im[4][kLdsWave];
-    __shared__ float s_w[kMaxNnz];
-    __shared__ int s_start[kNmels], s_len[kNmels], s_off[kNmels];
+    constexpr int NT = 64 * kFramesPerBlock;
+    __shared__ __attribute__((aligned(16))) float s_pl[kFramesPerBlock][kLdsPlane];
+    __shared__ __attribute__((aligned(16))) float s_w[kMaxNnzPad];   // band weights, every band padded to whole aligned quads of bins
+    __shared__ float2 s_tw[1024];                                    // W_2048^i, i < 1024: the post-process reads consecutive entries
+    __shared__ float2 s_tw23[1024];                                  // passes 2 and 3, lane-major (FrontendTables::tw23): no bank conflicts
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < T.nnz; i += 256) s_w[i] = T.mel_w[i];
-    if (tid < kNmels) { s_start[tid] = T.mel_start[tid]; s_len[tid] = T.mel_len[tid]; s_off[tid] = T.mel_off[tid]; }
-    __syncthreads();
+    for (int i = tid; i < T.nnz_pad / 4; i += NT) reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(T.mel_wp)[i];
+#pragma unroll
+    for (int i = 0; i < 1024 / NT; i++) { s_tw[tid + NT * i] = T.tw[tid + NT * i]; s_tw23[tid + NT * i] = T.tw23[tid + NT * i]; }
 
-    constexpr int FPB = kFramesPerBlock;
-    const int groups = (T.n_frames + FPB - 1) / FPB;
+    constexpr int fpb = kFramesPerBlock;
+    const int groups = (T.n_frames + fpb - 1) / fpb;
     const int win = blockIdx.x / groups, fg = blockIdx.x % groups;
-    if (win >= n_windows) return;
-    float *re = s_re[wave], *im = s_im[wave];
+    float *pl = s_pl[wave];
 
     const size_t win_off = (size_t)win * stride_bytes;
     long avail = 0;   // valid bytes of this window (model.go:88-96 pad/truncate)
-    if (win_off < total_bytes) {
+    if (win < n_windows && win_off < total_bytes) {
         size_t a = total_bytes - win_off;
         avail = (long)(a > (size_t)kSampleBytes ? (size_t)kSampleBytes : a);
     }
     const uint8_t *wp = pcm + win_off;
     const bool aligned4 = (((uintptr_t)wp) & 3) == 0;
 
-    // band pair owned by this lane (short band + long band, to balance the sparse dot)
+    // band pair owned by this lane (short band + long band, to balance the sparse dot): first quad of bins, quads, offset
     const int mA = lane, mB = kNmels - 1 - lane;
-    const int stA = s_start[mA], lnA = s_len[mA], ofA = s_off[mA];
-    const int stB = s_start[mB], lnB = s_len[mB], ofB = s_off[mB];
-    int maxlen = lnA > lnB ? lnA : lnB;
+    const int qsA = T.mel_start4[mA] >> 2, qnA = T.mel_len4[mA], qoA = T.mel_off4[mA] >> 2;
+    const int qsB = T.mel_start4[mB] >> 2, qnB = T.mel_len4[mB], qoB = T.mel_off4[mB] >> 2;
+    int maxq = qnA > qnB ? qnA : qnB;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(maxlen, o); maxlen = t > maxlen ? t : maxlen; }
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(maxq, o); maxq = t > maxq ? t : maxq; }
+    __syncthreads();
+    if (win >= n_windows) return;
 
-    for (int it = 0; it < FPB / 4; it++) {
-        const int frame = fg * FPB + it * 4 + wave;
-        if (frame >= T.n_frames) break;   // wave-uniform
+    {
+        const int frame = fg * fpb + wave;
+        if (frame >= T.n_frames) return;   // wave-uniform; no workgroup barrier follows
         const long s_begin = (long)T.frame_origin + (long)frame * kHop;   // first sample of the frame
 
         // ---- load + window: lane holds z[n] = x[2n] + i x[2n+1] for n = lane + 64 m ----
@@ -163,83 +192,72 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict
             v[m] = make_float2(x0 * (1.0f / 32768.0f) * w.x, x1 * (1.0f / 32768.0f) * w.y);
         }
 
-        // ---- pass 1: radix 16, Ns = 1 (no twiddles); out[16 j + t] ----
+        // ---- pass 1: radix 16, Ns = 1 (no twiddles); out[16 j + t] at pidx(16 lane + t); pass 2 reads x[j + 64 t] ----
         dft16(v);
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-            const int a = 17 * lane + t;   // pidx(16*lane + t)
-            re[a] = v[dft16_slot(t)].x;
-            im[a] = v[dft16_slot(t)].y;
-        }
-        wave_lds_sync();
+        const int rbase = lane + (lane >> 4);
+        APR_FE_EXCHANGE(17 * lane + t, dft16_slot(t), rbase + 68 * t)
 
-        // ---- pass 2: radix 16, Ns = 16; in x[j + 64 t] * W_256^(k t), out[(j/16)*256 + k + 16 t] ----
+        // ---- pass 2: radix 16, Ns = 16; x[j + 64 t] * W_256^(k t), out[(j/16)*256 + k + 16 t]; pass 3 reads x[j' + 256 t] ----
         {
             const int k = lane & 15;
-            const int rbase = lane + (lane >> 4);
 #pragma unroll
-            for (int t = 0; t < 16; t++) {
-                float2 x = make_float2(re[rbase + 68 * t], im[rbase + 68 * t]);
-                if (t > 0) x = cmul(x, T.tw[8 * k * t]);
-                v[t] = x;
-            }
-            wave_lds_sync();
+            for (int t = 1; t < 16; t++) v[t] = cmul(v[t], s_tw23[16 * t + k]);
             dft16(v);
             const int wbase = (lane >> 4) * 272 + k;
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
-                re[wbase + 17 * t] = v[dft16_slot(t)].x;
-                im[wbase + 17 * t] = v[dft16_slot(t)].y;
-            }
+            APR_FE_EXCHANGE(wbase + 17 * t, dft16_slot(t), rbase + 68 * t)
         }
-        wave_lds_sync();
 
-        // ---- pass 3: radix 4, Ns = 256; j' = lane + 64 q reads x[j' + 256 t] * W_1024^(j' t),
-        //      writes out[j' + 256 t] (same slots): Z[k] for k = lane + 64 m ends in v[m] ----
-        {
-            const int rbase = lane + (lane >> 4);
+        // ---- pass 3: radix 4, Ns = 256; j' = lane + 64 q: x[j' + 256 t] * W_1024^(j' t); Z[k] for k = lane + 64 m ends in v[m] ----
 #pragma unroll
-            for (int m = 0; m < 16; m++) v[m] = make_float2(re[rbase + 68 * m], im[rbase + 68 * m]);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int jp = lane + 64 * q;
-                v[q + 4] = cmul(v[q + 4], T.tw[2 * jp]);
-                v[q + 8] = cmul(v[q + 8], T.tw[4 * jp]);
-                v[q + 12] = cmul(v[q + 12], T.tw[6 * jp]);
-                dft4(v[q], v[q + 4], v[q + 8], v[q + 12]);
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int m = 0; m < 16; m++) { re[rbase + 68 * m] = v[m].x; im[rbase + 68 * m] = v[m].y; }
+        for (int q = 0; q < 4; q++) {
+            const int jp = lane + 64 * q;
+            v[q + 4] = cmul(v[q + 4], s_tw23[256 + jp]);
+            v[q + 8] = cmul(v[q + 8], s_tw23[512 + jp]);
+            v[q + 12] = cmul(v[q + 12], s_tw23[768 + jp]);
+            dft4(v[q], v[q + 4], v[q + 8], v[q + 12]);
         }
-        wave_lds_sync();
 
-        // ---- packed-real post-process: X[k] = (Z[k] + conj Z[N-k])/2 - i/2 W_2048^k (Z[k] - conj Z[N-k]) ----
+        // ---- packed-real post-process: X[k] = (Z[k] + conj Z[N-k])/2 - i/2 W_2048^k (Z[k] - conj Z[N-k]).
+        //      Z[N-k] sits in lane (64 - lane) & 63, register 15 - m (lane 0: its own register (16 - m) & 15): a lane
+        //      permute, no trip through the plane ----
         float pw[16];
         float p_nyq = 0.0f;
+        const int lsrc = (64 - lane) & 63;
 #pragma unroll
         for (int m = 0; m < 16; m++) {
             const int k = lane + 64 * m;
-            const int kr = (1024 - k) & 1023;
-            const float2 zr = make_float2(re[pidx(kr)], -im[pidx(kr)]);   // conj Z[N-k]
+            float zx = __shfl(v[15 - m].x, lsrc), zy = __shfl(v[15 - m].y, lsrc);
+            if (lane == 0) { zx = v[(16 - m) & 15].x; zy = v[(16 - m) & 15].y; }
+            const float2 zr = make_float2(zx, -zy);   // conj Z[N-k]
             const float2 e = cadd(v[m], zr), o = csub(v[m], zr);
-            const float2 wo = mul_mi(cmul(T.tw[k], o));
+            const float2 wo = mul_mi(cmul(s_tw[k], o));
             const float xr = 0.5f * (e.x + wo.x), xi = 0.5f * (e.y + wo.y);
             pw[m] = xr * xr + xi * xi;
             if (m == 0) { const float d = v[0].x - v[0].y; p_nyq = d * d; }   // only lane 0's is bin 1024
+            if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four bins at a time: keeps the permutes and twiddles of all 16 from being live together
         }
-        wave_lds_sync();
-        // power spectrum P[0..1024] overwrites the real plane (unpadded)
+        // power spectrum P[0..1024] into the plane (unpadded); the quads of the last bands may reach a little further: zeros
 #pragma unroll
-        for (int m = 0; m < 16; m++) re[lane + 64 * m] = pw[m];
-        if (lane == 0) re[1024] = p_nyq;
+        for (int m = 0; m < 16; m++) pl[lane + 64 * m] = pw[m];
+        if (lane == 0) pl[1024] = p_nyq;
+        if (lane >= 1 && lane < 8) pl[1024 + lane] = 0.0f;
         wave_lds_sync();
 
-        // ---- sparse mel projection (dsp.go:83-111): k-ascending sequential sum per band ----
+        // ---- sparse mel projection (dsp.go:83-111): k-ascending sequential sum per band.  Four bins per LDS read on
+        //      both operands; the padding weights are +0, and fma(+0, p, acc) = acc exactly, so the sum is the
+        //      unpadded one bit for bit ----
         float accA = 0.0f, accB = 0.0f;
-        for (int i = 0; i < maxlen; i++) {
-            if (i < lnA) accA = fmaf(s_w[ofA + i], re[stA + i], accA);
-            if (i < lnB) accB = fmaf(s_w[ofB + i], re[stB + i], accB);
+        const float4 *P4 = reinterpret_cast<const float4 *>(pl);
+        const float4 *W4 = reinterpret_cast<const float4 *>(s_w);
+        for (int i = 0; i < maxq; i++) {
+            if (i < qnA) {
+                const float4 p = P4[qsA + i], w = W4[qoA + i];
+                accA = fmaf(w.x, p.x, accA); accA = fmaf(w.y, p.y, accA); accA = fmaf(w.z, p.z, accA); accA = fmaf(w.w, p.w, accA);
+            }
+            if (i < qnB) {
+                const float4 p = P4[qsB + i], w = W4[qoB + i];
+                accB = fmaf(w.x, p.x, accB); accB = fmaf(w.y, p.y, accB); accB = fmaf(w.z, p.z, accB); accB = fmaf(w.w, p.w, accB);
+            }
         }
         float *dst = melT + ((size_t)win * kSpecFrames + frame) * kNmels;
         dst[mA] = accA;
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const uint8_t *__restrict
         wave_lds_sync();
     }
 }
+#undef APR_FE_EXCHANGE
 
 // ---------------------------------------------------------------------------------------------
 // Kernel 2: dB + normalise + transpose.  powerToDb / fixedNormalize (dsp.go:114-155) and the pack
