@@ -24,6 +24,7 @@ SYMBOLS = (
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
     "apr_resample_taps", "apr_upsample", "apr_upsample_device", "apr_stream_tick", "apr_stream_buffer", "apr_stream_reset",
     "apr_prepare_batch_device_static", "apr_engine_create_ex", "apr_sweep_plan", "apr_sweep_files_multi",
+    "apr_bucket_hits_device",
 )
 
 
@@ -109,6 +110,8 @@ def lib():
     L.apr_wav_data_offset.restype = C.c_size_t
     L.apr_bucket_hits.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]
     L.apr_bucket_hits.restype = C.c_int
+    L.apr_bucket_hits_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]
+    L.apr_bucket_hits_device.restype = C.c_int
     L.apr_resample_taps.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, vp]
     L.apr_resample_taps.restype = C.c_int
     L.apr_upsample.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp]

@@ -22,6 +22,7 @@
 #include "model_parse.h"
 #include "wino.hip.h"
 #include "resample.hip.h"
+#include "report.hip.h"
 #include "conv12_fused.hip.h"
 #include "wino_fused.hip.h"
 #include "wino_fused8.hip.h"
@@ -1346,6 +1347,24 @@ int apr_upsample(apr_engine *e, const int16_t *in, size_t n_in, int up, const do
         HIPCHK(e, hipMemcpyAsync(out + m0 * (size_t)up, e->d_rs_out, (size_t)n_count * sizeof(int16_t), hipMemcpyDeviceToHost, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
     }
+    return APR_OK;
+}
+
+int apr_bucket_hits_device(apr_engine *e, const int32_t *d_label, const uint8_t *d_match, size_t n_windows, int n_classes,
+                           size_t windows_per_bucket, uint8_t *d_hits)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (n_classes < 1 || n_classes > APR_MAX_CLASSES || !windows_per_bucket || (n_windows && (!d_label || !d_match || !d_hits))) {
+        e->err = "apr_bucket_hits_device: bad argument (1 <= n_classes <= 64, windows_per_bucket > 0)";
+        return APR_ERR_INVALID;
+    }
+    if (!n_windows) return APR_OK;
+    const unsigned long long nb = (n_windows + windows_per_bucket - 1) / windows_per_bucket;
+    const unsigned blocks = (unsigned)std::min<unsigned long long>((nb + 3) / 4, 256 * 8);   // one wave per bucket, grid-stride beyond that
+    hipLaunchKernelGGL(apr::bucket_hits_kernel, dim3(blocks), dim3(256), 0, e->stream, d_label, d_match, (unsigned long long)n_windows, n_classes,
+                       (unsigned long long)windows_per_bucket, nb, d_hits);
+    HIPCHK(e, hipGetLastError());
     return APR_OK;
 }
 

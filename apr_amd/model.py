@@ -278,6 +278,11 @@ class Engine:
         self._chk(self._lib.apr_prepare_batch_device_static(self._h, flavour, _addr(d_pcm), total_bytes, n_windows, stride,
                                                             _addr(d_out)))
 
+    def bucket_hits_device(self, d_label, d_match, n_windows: int, n_classes: int, d_hits, windows_per_bucket: int = 60) -> None:
+        """apr_bucket_hits_device: one hit per class per minute from device-resident (label, match) rows."""
+        self._chk(self._lib.apr_bucket_hits_device(self._h, _addr(d_label), _addr(d_match), n_windows, n_classes,
+                                                   windows_per_bucket, _addr(d_hits)))
+
     def infer_device(self, d_spec, batch: int, d_logits) -> None:
         self._chk(self._lib.apr_infer_device(self._h, _addr(d_spec), batch, _addr(d_logits)))
 

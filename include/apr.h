@@ -286,6 +286,11 @@ int apr_upsample_device(apr_engine *e, const int16_t *d_in, size_t n_in, int up,
  */
 int apr_bucket_hits(const int32_t *label, const uint8_t *match, size_t n_windows, int n_classes, size_t windows_per_bucket,
                     uint8_t *hits);
+/* The same on the GPU, for (label, match) rows that are still in HBM -- the outputs of apr_score_device / apr_classify_device
+ * or the gathered rows of a multi-GPU sweep: only [buckets][n_classes] bytes then travel to the host.  Device pointers;
+ * every byte of d_hits is written; n_classes <= APR_MAX_CLASSES.  Asynchronous on the engine's stream. */
+int apr_bucket_hits_device(apr_engine *e, const int32_t *d_label, const uint8_t *d_match, size_t n_windows, int n_classes,
+                           size_t windows_per_bucket, uint8_t *d_hits);
 
 /* Block until all work queued on this engine's stream has finished. */
 int apr_sync(apr_engine *e);

@@ -175,3 +175,36 @@ def test_infer_engine_cache_is_keyed_by_content(he_weights, clips):
     lb = oracle.softmax(oracle.cnn_forward(w2, 4, spec.reshape(1, 128, 188))[0])
     assert abs(rb[LABELS[3]] - lb[3]) <= 1e-4
     assert model.Unload(mb) == 1 and model.Unload(ma) == 2 and model.Unload() >= 1
+
+
+def test_bucket_hits_on_the_gpu_equals_the_host_form(he_weights):
+    # one hit per class per minute (docs/usage/review.md:48-53) over rows that are still in HBM
+    import torch
+    dev = torch.device("cuda", 0)
+    fe = model.Engine(None, 0, 8)
+    rng = np.random.default_rng(8)
+    for n, C, wpb in ((0, 4, 60), (1, 4, 60), (59, 4, 60), (60, 4, 60), (61, 4, 60), (35999, 4, 60), (100000, 64, 7), (5000, 1, 600)):
+        label = rng.integers(-1, C + 1, n).astype(np.int32)           # -1 (no label) and C (out of range) must be ignored
+        match = (rng.random(n) < 0.05).astype(np.uint8)
+        want = sweep.bucket_hits(np.where(label < C, label, -1), match, C, wpb)
+        nb = (n + wpb - 1) // wpb
+        d_hits = torch.full((max(nb, 1), C), 7, dtype=torch.uint8, device=dev)
+        fe.bucket_hits_device(torch.from_numpy(label).to(dev), torch.from_numpy(match).to(dev), n, C, d_hits, wpb)
+        fe.sync()
+        assert np.array_equal(d_hits.cpu().numpy()[:nb], want), (n, C, wpb)
+    with pytest.raises(AprError):
+        fe.bucket_hits_device(d_hits, d_hits, 10, 65, d_hits)
+    # on the output of a real sweep, without the rows leaving the GPU
+    eng = model.Engine(W.pack_blob(he_weights, 4), 0, 64)
+    pcm = model.synth_pcm(2, 1, 150)
+    n = model.windows_in(pcm.nbytes)
+    d_pcm = torch.from_numpy(pcm.view(np.uint8).copy()).to(dev)
+    d_label = torch.empty(n, dtype=torch.int32, device=dev)
+    d_match = torch.empty(n, dtype=torch.uint8, device=dev)
+    eng.score_device(d_pcm, d_pcm.numel(), n, 96000, 0.26, -1, None, d_label, d_match)   # no "empty" class: every window matches some class
+    d_hits = torch.empty(((n + 59) // 60, 4), dtype=torch.uint8, device=dev)
+    eng.bucket_hits_device(d_label, d_match, n, 4, d_hits)
+    eng.sync()
+    assert np.array_equal(d_hits.cpu().numpy(), sweep.bucket_hits(d_label.cpu().numpy(), d_match.cpu().numpy(), 4))
+    assert d_match.sum().item() > 0
+    fe.close(); eng.close()
