@@ -2,9 +2,9 @@
 """Copy the round's rocprofv3 outputs (tools/profile_round.sh -> gpurun_out/) into profiles/ as compact summaries."""
 import collections, csv, json, re, shutil, subprocess, sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 subprocess.check_call([sys.executable, "tools/pmc_traffic.py", "gpurun_out/pmc_fetch", "gpurun_out/pmc_write", f"profiles/{R}_pmc_traffic.json"])
-shutil.copy("gpurun_out/prof_r1b/p_kernel_stats.csv", f"profiles/{R}_bench_kernel_stats.csv")
+shutil.copy("gpurun_out/prof_round/p_kernel_stats.csv", f"profiles/{R}_bench_kernel_stats.csv")
 shutil.copy("gpurun_out/bench_prof_b.json", f"profiles/{R}_bench_under_rocprof.json")
 
 
