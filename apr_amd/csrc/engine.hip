@@ -916,6 +916,8 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
     }
     apr_engine *e = new (std::nothrow) apr_engine();
     if (!e) { g_create_err = "out of host memory"; return APR_ERR_NOMEM; }
+    // released on every way out but success, a std::bad_alloc from the table / weight containers below included
+    struct Guard { apr_engine *e; ~Guard() { if (e) apr_engine_destroy(e); } } guard{e};
     e->device = device_id;
     e->max_batch = max_batch > 0 ? std::min(max_batch, 16384) : 1024;   // keeps every layer's pixel count < 2^31
     add_slot(e, "stft_mel_kernel", -1);
@@ -974,9 +976,9 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
     }
     if (rc) {
         g_create_err = e->err;
-        apr_engine_destroy(e);
         return rc;
     }
+    guard.e = nullptr;
     *out = e;
     return APR_OK;
 }
