@@ -27,6 +27,7 @@
 #include "wino_fused.hip.h"
 #include "wino_fused8.hip.h"
 #include "wino_s2.hip.h"
+#include "wino_s2_fused.hip.h"
 
 using namespace apr;
 
@@ -66,7 +67,8 @@ struct Layer {
     int bn_tile = 0, bm_tile = 128;
     // Winograd F(2x2,3x3) path (stride-1 layers with enough channels to amortise the transforms)
     int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2),
-                            // 4 = stride 2 in polyphase Winograd F(2,2) form (wino_s2.hip.h: 25 GEMMs + output transform)
+                            // 4 = stride 2 in polyphase Winograd F(2,2) form (wino_s2.hip.h: 25 GEMMs + output transform),
+                            // 5 = the same in one kernel (wino_s2_fused.hip.h)
     int fused_waves = 8;    // wino == 3: wino_fused8_f2 (8 waves a block) or wino_fused_f2 (4)
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
     int th = 0, tw = 0;     // 2x2-output tiles per window
@@ -453,6 +455,25 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             v_max = std::max(v_max, (size_t)16 * L.th * L.tw * cv.cin);
             m_max = std::max(m_max, (size_t)L.wsplit * 16 * L.th * L.tw * cv.cout);
         }
+        // the one-kernel form (wino_s2_fused.hip.h): engines of >= 1024 windows (enough 32-tile units to fill the chip);
+        // APR_WINO_S2_FUSED=0 turns it off, APR_WINO_S2_FUSED_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests)
+        {
+            const char *sfenv = getenv("APR_WINO_S2_FUSED");
+            const bool s2f_on = wino_s2_on && !(sfenv && sfenv[0] == '0');
+            const int s2f_min_cin = getenv("APR_WINO_S2_FUSED_MIN_CIN") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_CIN")) : 128;
+            const int s2f_min_px = getenv("APR_WINO_S2_FUSED_MIN_PX") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_PX")) : 24;
+            const int s2f_min_batch = getenv("APR_WINO_S2_FUSED_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_BATCH")) : 1024;
+            if (!L.wino && s2f_on && l > 0 && cv.stride == 2 && cv.cin >= s2f_min_cin && cv.cin % 32 == 0 && cv.cout % WS_BN == 0 &&
+                L.hout * L.wout >= s2f_min_px && e->max_batch >= s2f_min_batch) {
+                std::vector<float> u((size_t)16 * cv.cin * cv.cout);
+                ws_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
+                if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+                L.wino = 5;
+                L.ksplit = 1;
+                L.th = (L.hout + 1) / 2;
+                L.tw = (L.wout + 1) / 2;
+            }
+        }
         if (!L.wino && wino_s2_on && l > 0 && cv.stride == 2 && cv.cin >= wino_s2_min_cin && cv.cin % 16 == 0 && cv.cout % 128 == 0 &&
             L.hout * L.wout >= wino_s2_min_px && e->max_batch >= wino_s2_min_batch) {
             std::vector<float> u((size_t)16 * cv.cin * cv.cout);
@@ -623,6 +644,21 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             else
                 hipLaunchKernelGGL(wino_fused8_f2, dim3(wf8_grid((int)(tiles_m * tiles_n), e->n_cus)), dim3(512), WF8_LDS_BYTES, e->stream, in, L.d_u,
                                    L.d_b, out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw), (int)(tiles_m * tiles_n));
+            in = out;
+            continue;
+        }
+        if (L.wino == 5) {
+            const long long T = (long long)batch * L.th * L.tw;   // < 2^31: max_batch is capped at create
+            const int tiles_n = L.cout / WS_BN;
+            const long long tiles_m = (T + WS_TT - 1) / WS_TT;
+            ProfScope ps(e, L.slot, 2.0 * 25.0 * (double)T * L.cin * L.cout, bytes + 4.0 * 7.0 * L.cin * L.cout);
+            WsArgs wa;
+            wa.in = in; wa.up = L.d_u; wa.bias = L.d_b; wa.out = out;
+            wa.H = L.hin; wa.W = L.win; wa.Cin = L.cin; wa.Ho = L.hout; wa.Wo = L.wout; wa.Cout = L.cout;
+            wa.th = L.th; wa.tw = L.tw; wa.T = (int)T; wa.tiles_n = tiles_n;
+            wa.mg = wf_magic(tiles_n, L.th, L.tw);
+            const int n_units = (int)(tiles_m * tiles_n);
+            hipLaunchKernelGGL(wino_s2_fused, dim3(wf8_grid(n_units, e->n_cus)), dim3(512), WS_LDS_BYTES, e->stream, wa, n_units);
             in = out;
             continue;
         }
@@ -934,6 +970,10 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
     }
     if (!rc && (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || e->n_cus < 1)) e->n_cus = 256;
     if (!rc && !resolve_scratch(device_id, e->err)) rc = APR_ERR_DEVICE;   // this device's address of the static scratch array
+    if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(wino_s2_fused), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess) {
+        e->err = "could not reserve LDS for wino_s2_fused";
+        rc = APR_ERR_DEVICE;
+    }
     if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(conv12_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, C12_LDS_BYTES) != hipSuccess) {
         e->err = "could not reserve LDS for conv12_fused_kernel";
         rc = APR_ERR_DEVICE;
@@ -951,6 +991,7 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
             if (e->fuse12 && l == 0) continue;   // no kernel of its own
             if (e->fuse12 && l == 1) snprintf(nm, sizeof nm, "conv12_fused_kernel");
             else if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
+            else if (L.wino == 5) snprintf(nm, sizeof nm, "wino_s2_fused");
             else if (L.wino == 4) snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 3>", L.wbm_tile);
             else if (L.wino) {
                 L.slot_in = e->n_slots;

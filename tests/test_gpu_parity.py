@@ -310,6 +310,41 @@ def test_stride2_polyphase_winograd_layers(he_weights, monkeypatch):
     assert np.array_equal(s2, s2b)
 
 
+def test_stride2_fused_polyphase_winograd_layers(he_weights, monkeypatch):
+    # The same stride-2 form in ONE kernel (wino_s2_fused.hip.h; engines of max_batch >= 1024 use it from layer 4 on).  Forced here on
+    # every stride-2 layer from 4 to 12 in small engines: odd widths (94 -> 47 outputs -> 24 tiles of 2), the 2x3 image of layer 12
+    # (units of 32 tiles span 16 windows), ragged last units; against the reference's logits, the direct kernels and the
+    # nine-sum GEMM form.
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
+    blob = W.pack_blob(he_weights, 4)
+
+    def run(env, batch, x=specs):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = model.Engine(blob, 0, batch)
+        for k in env:
+            monkeypatch.delenv(k)
+        out = e.infer_logits(x)
+        e.close()
+        return out
+
+    fused = {"APR_WINO_S2_FUSED_MIN_BATCH": "1", "APR_WINO_S2_FUSED_MIN_CIN": "128", "APR_WINO_S2_FUSED_MIN_PX": "1"}
+    gemm = {"APR_WINO_S2_FUSED": "0", "APR_WINO_S2_MIN_BATCH": "1", "APR_WINO_S2_MIN_CIN": "128", "APR_WINO_S2_MIN_PX": "1"}
+    base = run({"APR_WINO_S2": "0"}, 8)
+    f8 = run(fused, 8)
+    f5 = run(fused, 5)                                 # six clips in chunks of 5 and 1: other unit boundaries
+    g8 = run(gemm, 8)
+    assert np.abs(f8 - want).max() <= LOGIT_TOL
+    assert np.abs(f8 - base).max() <= 2e-5 and not np.array_equal(f8, base)
+    assert np.abs(f8 - g8).max() <= 2e-5               # same products, other summation order
+    assert np.array_equal(f8, f5)
+    # 40 clips: layer 12's 80 tiles = 2.5 units, layer 4's 15 360 tiles = 480 units
+    many = np.concatenate([specs] * 7)[:40]
+    f40 = run(fused, 40, many)
+    assert np.array_equal(f40[:6], f8) and np.array_equal(f40[36:40], f8[:4])
+
+
 def test_sweep_files_equals_per_file_score(he_weights):
     # ragged list: packed into shared passes, split across passes, empty and too-short files, short tail windows
     eng = model.Engine(W.pack_blob(he_weights, 4), 0, 16)
