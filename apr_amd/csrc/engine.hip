@@ -455,14 +455,16 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             v_max = std::max(v_max, (size_t)16 * L.th * L.tw * cv.cin);
             m_max = std::max(m_max, (size_t)L.wsplit * 16 * L.th * L.tw * cv.cout);
         }
-        // the one-kernel form (wino_s2_fused.hip.h): engines of >= 1024 windows (enough 32-tile units to fill the chip);
+        // the one-kernel form (wino_s2_fused.hip.h): every stride-2 layer from Cin = 128 on in engines of >= 128 windows (a step of
+        // 2048-window passes: layers 4 / 6 / 8 / 10 / 12 = 103.8 / 95.9 / 91.9 / 23.0 / 29.1 ms against 117.2 direct, 104.8 / 94.9 / 24.1 as
+        // nine-sum GEMMs + output transform, 30.6 direct; 256 live streams: 8.8 against 9.0 ms a tick);
         // APR_WINO_S2_FUSED=0 turns it off, APR_WINO_S2_FUSED_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests)
         {
             const char *sfenv = getenv("APR_WINO_S2_FUSED");
             const bool s2f_on = wino_s2_on && !(sfenv && sfenv[0] == '0');
             const int s2f_min_cin = getenv("APR_WINO_S2_FUSED_MIN_CIN") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_CIN")) : 128;
-            const int s2f_min_px = getenv("APR_WINO_S2_FUSED_MIN_PX") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_PX")) : 24;
-            const int s2f_min_batch = getenv("APR_WINO_S2_FUSED_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_BATCH")) : 1024;
+            const int s2f_min_px = getenv("APR_WINO_S2_FUSED_MIN_PX") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_PX")) : 1;
+            const int s2f_min_batch = getenv("APR_WINO_S2_FUSED_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_BATCH")) : 128;
             if (!L.wino && s2f_on && l > 0 && cv.stride == 2 && cv.cin >= s2f_min_cin && cv.cin % 32 == 0 && cv.cout % WS_BN == 0 &&
                 L.hout * L.wout >= s2f_min_px && e->max_batch >= s2f_min_batch) {
                 std::vector<float> u((size_t)16 * cv.cin * cv.cout);

@@ -136,13 +136,22 @@ __device__ __forceinline__ void ws_rows(f32x2 (&d)[25])
         d[jj] = t0; d[5 + jj] = t1; d[10 + jj] = t2; d[15 + jj] = t3; d[20 + jj] = t4;
     }
 }
-// columns of transformed row i, and its five LDS stores into V image `buf`
-__device__ __forceinline__ void ws_cols_store(const WsCtx &c, const f32x2 (&d)[25], int buf, int i)
+// columns: d <- d B per transformed row, in place: row i becomes [r0 - r2, r1, r2, r3, r4 - r2] (positions 0, 3, 1, 4, 2)
+__device__ __forceinline__ void ws_cols(f32x2 (&d)[25])
+{
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        d[5 * i] = wf_sub2(d[5 * i], d[5 * i + 2]);
+        d[5 * i + 4] = wf_sub2(d[5 * i + 4], d[5 * i + 2]);
+    }
+}
+// the five LDS stores of transformed row i into V image `buf` (after ws_rows and ws_cols)
+__device__ __forceinline__ void ws_store_row(const WsCtx &c, const f32x2 (&d)[25], int buf, int i)
 {
     float *vs = c.Vs + buf * WS_VIMG + (5 * i) * (WS_TT * WS_BK) + c.st_off;
-    *reinterpret_cast<f32x2 *>(vs + 0 * (WS_TT * WS_BK)) = wf_sub2(d[5 * i], d[5 * i + 2]);
+    *reinterpret_cast<f32x2 *>(vs + 0 * (WS_TT * WS_BK)) = d[5 * i];
     *reinterpret_cast<f32x2 *>(vs + 1 * (WS_TT * WS_BK)) = d[5 * i + 2];
-    *reinterpret_cast<f32x2 *>(vs + 2 * (WS_TT * WS_BK)) = wf_sub2(d[5 * i + 4], d[5 * i + 2]);
+    *reinterpret_cast<f32x2 *>(vs + 2 * (WS_TT * WS_BK)) = d[5 * i + 4];
     *reinterpret_cast<f32x2 *>(vs + 3 * (WS_TT * WS_BK)) = d[5 * i + 1];
     *reinterpret_cast<f32x2 *>(vs + 4 * (WS_TT * WS_BK)) = d[5 * i + 3];
 }
@@ -171,7 +180,7 @@ __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc
                                          f32x2 (&d)[25], const unsigned (&vo)[25])
 {
     constexpr int NP = ws_np(Q);
-    constexpr int ROLE = (Q - PH + 4) & 3;   // 3: load chunk kc+3, 2: DMA quarter 2+wn, 1: transform + store chunk kc+1, 0: DMA quarter wn
+    constexpr int ROLE = (Q - PH + 4) & 3;   // 3: load chunk kc+3, 2: DMA quarter 2+wn and transform chunk kc+2, 1: store chunk kc+1, 0: DMA quarter wn
     constexpr int SET0 = (PH * NP) & 1;      // operand register set of this step's first position
     const int kn1 = kc + 1 < c.KC ? kc + 1 : c.KC - 1;   // chunk indices past the end are clamped (staging nobody reads)
     const int kn3 = kc + 3 < c.KC ? kc + 3 : c.KC - 1;
@@ -198,10 +207,13 @@ __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc
                 if (sl < 24) d[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u.rsA, vo[sl], 4 * kn3 * WS_BK, 0));
                 if (sl == 23) d[24] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u.rsA, vo[24], 4 * kn3 * WS_BK, 0));
             }
-            if (ROLE == 1 && !(WS_ABL & 8)) {
-                if (sl == 0) ws_rows(d);
-                if (sl >= 2 && sl <= 14 && (sl - 2) % 3 == 0) ws_cols_store(c, d, cur ^ 1, (sl - 2) / 3);
+            // B^T d B of chunk kc+2 already in the DMA step before its store step (its loads went out a step ago): the store
+            // step of a wave pair, whose non-MFMA work both waves of one SIMD do at the same time, is left with the stores
+            if (ROLE == 2 && !(WS_ABL & 8)) {
+                if (sl == 14) ws_rows(d);
+                if (sl == 17) ws_cols(d);
             }
+            if (ROLE == 1 && !(WS_ABL & 8) && sl >= 1 && sl <= 13 && (sl - 1) % 3 == 0) ws_store_row(c, d, cur ^ 1, (sl - 1) / 3);
             if (!(WS_ABL & 2) && (ROLE == 0 || ROLE == 2) && sl >= 1 && sl <= 8) {   // U(kc+1): this wave's quarter, 1 KiB a slot
                 const unsigned uv = ROLE == 0 ? c.uvoff0 : c.uvoff3, ul = ROLE == 0 ? c.us_lds0 : c.us_lds3;
                 lds_dma_b128(u.rsU, uv, __builtin_amdgcn_readfirstlane(kn1 * (WS_UIMG * 4) + (sl - 1) * 1024),
@@ -237,10 +249,13 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         for (int s = 0; s < 3; s++) acc[s] = zero16;
         // ---- prologue: the unit's first loads are already in flight (issued above, or before the previous unit's epilogue);
         //      group 0 stages chunk 0, groups 2 and 3 see their DMA of U(0) land (group 2: and its chunk 2) ----
-        if (Q == 0) {
+        if (Q == 0 || Q == 1) {   // chunks 0 and 1 have no DMA step before their store step
             ws_rows(d);
+            ws_cols(d);
+        }
+        if (Q == 0) {
 #pragma unroll
-            for (int i = 0; i < 5; i++) ws_cols_store(c, d, 0, i);
+            for (int i = 0; i < 5; i++) ws_store_row(c, d, 0, i);
         }
         if (Q == 2 || Q == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
