@@ -1665,3 +1665,12 @@ int apr_profile_read(apr_engine *e, apr_profile_slot *slots, int *n_slots)
 }
 
 }  // extern "C"
+
+#ifdef WS_STAMPS   // developer build (tools/ws_stamps.py)
+extern "C" int apr_debug_ws_stamps(unsigned long long *dst, int reset)
+{
+    static const unsigned long long zero[64] = {};
+    if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(apr::ws_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(apr::ws_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

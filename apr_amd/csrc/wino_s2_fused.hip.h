@@ -9,18 +9,25 @@
 // Work unit = 32 tiles (2x2 outputs each) x 64 channels, one workgroup of 8 waves per CU.  Wave = (channel half wn, q):
 // the four waves q of a 32 x 32 sub-block split the nine sums -- and with them the 25 positions -- 6 / 6 / 6 / 7:
 //     q0: S00 (4 positions) + S01 (2)      q1: S02 (4) + S12 (2)      q2: S20 (4) + S10 (2)      q3: S22 (4) + S21 (2) + S11 (1)
-// i.e. 32 or 48 accumulator registers a wave.  Waves w and w + 4 share a SIMD (tools/probe/hwid.hip) and a q: they run the
-// same instruction stream in step.  (Measured and dropped: q = (w + wn) & 3, which spreads the two 7-position waves and the
-// two waves of a staging group over different SIMDs, 2-4 % slower; S11 shared between the four waves, one k-pair each, so
-// that every wave issues 25 MFMAs a step, 3 % slower.)
+// i.e. 32 or 48 accumulator registers a wave -- except that S11 of channel half 1 goes to the q0 wave of that half (position
+// sets, ws_tab), so that the SIMDs issue 52 / 48 / 48 / 52 MFMAs a step instead of 48 / 48 / 48 / 56.  Waves w and w + 4 share a
+// SIMD (tools/probe/hwid.hip) and a q.  They do NOT run in step: the SIMD serves the older wave (w, channel half 0) first, so
+// that wave reaches the step's barrier ~2 k cycles before its partner, and its staging instructions run beside the partner's
+// MFMAs while the partner's own are exposed (s_memtime stamps, -DWS_STAMPS + tools/ws_stamps.py; timing ablations: staging
+// by the waves of half 0 alone costs 3 % of the step, by those of half 1 alone 6.5 %).  Hence the whole U DMA is the work of
+// the half-0 waves.  (Measured and dropped: q = (w + wn) & 3, which spreads the two 7-position waves and the two waves of a
+// staging group over different SIMDs, 2-4 % slower; S11 shared between the four waves, one k-pair each, so that every wave
+// issues 25 MFMAs a step, 3 % slower; U straight from global memory into the B operand registers, no LDS image: 1.5 % slower
+// -- the bytes through the vector memory path cost the time, not the LDS reads; three staging groups q0-q2 with the
+// 7-position waves exempt: 1-2 % slower; the half-0 waves staging whole chunks with 16-B loads: 2-4 % slower.)
 // K step = 8 input channels, double-buffered LDS images
 //     Vs[25 positions][32 tiles][8]  (25 KiB)      Us[16 weight matrices][64 channels][8]  (32 KiB; positions 3 and 4 of an axis share one)
 // one barrier per K step.  The staging of a chunk is the work of ONE wave pair (q = chunk mod 4; 128 lanes = 32 tiles x 4
 // channel pairs): it loads the chunk's 5 x 5 patches THREE steps ahead (two whole K steps of latency: first touches come
-// from HBM), transforms and stores them one step ahead, and DMAs a quarter of U in the two steps in between and after:
-//     step k:  group (k+3)%4 loads chunk k+3 | group (k+1)%4 transforms chunk k+1 | groups (k+2)%4 and k%4 DMA U(k+1)
-// (a DMA wave waits vmcnt(0) before the step's barrier; for group (k+2)%4 that covers its patch loads too, issued a step
-// earlier and long landed)
+// from HBM), transforms them two steps ahead and stores them one step ahead; its half-0 wave copies U in the two other steps:
+//     step k:  group (k+3)%4 loads chunk k+3 | group (k+2)%4 transforms chunk k+2 |
+//              group (k+1)%4 stores chunk k+1 and DMAs 12 KiB of U(k+1) | group k%4 DMAs 20 KiB of U(k+1)
+// (a DMA wave waits vmcnt(0) before the step's barrier: nothing else of its own is in flight then)
 // The K loop is unrolled by four, so a wave's role in every step is a compile-time constant of its code path (one path
 // per q).  Workgroups are persistent (one per CU, the units cut into 8 XCD-contiguous runs): after a unit's K loop the next
 // unit's tile table, patch offsets, first patch loads (chunks 0 and 1) and first U DMA go out, so their latency runs under
@@ -43,21 +50,40 @@ constexpr int WS_LDS_BYTES = (2 * WS_VIMG + 2 * WS_UIMG) * 4 + 2 * WS_TT * 16;
 static_assert(WS_UIMG == WF_POS, "U images share wf_pack_u's layout");
 static_assert(2 * 4 * 16 * 64 * 4 <= WS_UIMG * 4 && 2 * 16 * 64 * 4 <= WS_VIMG * 4, "the epilogue's exchange fits the second staging buffers");
 
+#ifndef WS_DMA0
+#define WS_DMA0 20   // KiB of a U image copied by the wave whose step has no other staging work (the rest: the wave of the store step; in the transform step hipcc's counted waits for the patch loads would cover the DMA: 16 KiB there cost 3 %)
+#endif
 #ifndef WS_ABL
 #define WS_ABL 0   // developer timing ablations (wrong results): 1 no wait for the U DMA, 2 no U DMA, 4 no patch loads, 8 no transform / stores
 #endif
 
 // positions of wave q: n-th entry = (patch-transform row pi, column pj, accumulator slot)
-__host__ __device__ constexpr int ws_np(int q) { return q == 3 ? 7 : 6; }
-__host__ __device__ constexpr int ws_tab(int q, int n, int f)
+// Position sets: 0..3 = the sums of q = 0..3 as listed above; S11 of channel half 1 is accumulated by the q = 0 wave of that half
+// instead of its q = 3 wave (set 4 = set 0 + S11, set 5 = set 3 without S11), so that the four SIMDs issue 52 / 48 / 48 / 52 MFMAs
+// a step instead of 48 / 48 / 48 / 56.
+__host__ __device__ constexpr int ws_np(int ps) { return ps == 3 || ps == 4 ? 7 : 6; }
+__host__ __device__ constexpr int ws_q(int ps) { return ps < 4 ? ps : ps == 4 ? 0 : 3; }
+__host__ __device__ constexpr int ws_tab(int ps, int n, int f)
 {
-    constexpr int T[4][7][3] = {{{0, 0, 0}, {0, 3, 0}, {3, 0, 0}, {3, 3, 0}, {0, 1, 1}, {3, 1, 1}, {0, 0, 0}},
+    constexpr int T[6][7][3] = {{{0, 0, 0}, {0, 3, 0}, {3, 0, 0}, {3, 3, 0}, {0, 1, 1}, {3, 1, 1}, {0, 0, 0}},
                                 {{0, 2, 0}, {0, 4, 0}, {3, 2, 0}, {3, 4, 0}, {1, 2, 1}, {1, 4, 1}, {0, 0, 0}},
                                 {{2, 0, 0}, {2, 3, 0}, {4, 0, 0}, {4, 3, 0}, {1, 0, 1}, {1, 3, 1}, {0, 0, 0}},
-                                {{2, 2, 0}, {2, 4, 0}, {4, 2, 0}, {4, 4, 0}, {2, 1, 1}, {4, 1, 1}, {1, 1, 2}}};
-    return T[q][n][f];
+                                {{2, 2, 0}, {2, 4, 0}, {4, 2, 0}, {4, 4, 0}, {2, 1, 1}, {4, 1, 1}, {1, 1, 2}},
+                                {{0, 0, 0}, {0, 3, 0}, {3, 0, 0}, {3, 3, 0}, {0, 1, 1}, {3, 1, 1}, {1, 1, 2}},
+                                {{2, 2, 0}, {2, 4, 0}, {4, 2, 0}, {4, 4, 0}, {2, 1, 1}, {4, 1, 1}, {0, 0, 0}}};
+    return T[ps][n][f];
 }
 __host__ __device__ constexpr int ws_umap(int p) { return p < 3 ? p : 3; }            // U = [w0, w0 + w2, w2, w1, w1]
+
+#ifdef WS_STAMPS   // developer build (tools/ws_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles waited at the barrier
+                   // of the steps of each phase, K loop total, steps
+__device__ unsigned long long ws_stamps[8][8];
+#define WS_ST_ARG , unsigned (&st)[8]
+#define WS_ST_PASS , st
+#else
+#define WS_ST_ARG
+#define WS_ST_PASS
+#endif
 
 struct WsArgs {
     const float *in, *up, *bias;
@@ -69,7 +95,7 @@ struct WsArgs {
 struct WsCtx {   // per-wave constants of the whole launch
     float *Vs, *Us;
     unsigned *tbl;                               // [2][32][4]
-    unsigned uvoff0, uvoff3, us_lds0, us_lds3;   // the wave's quarter of a U image as DMA role 0 (quarter wn) / role 2 (quarter 2 + wn)
+    unsigned dma_v, us_lds;                      // U DMA: this lane's 16 B of a 1-KiB row; LDS address of Us[0]
     int st_off, rd_v, rd_u, KC, lane, wn, t_ld, cp;
 };
 
@@ -156,15 +182,21 @@ __device__ __forceinline__ void ws_store_row(const WsCtx &c, const f32x2 (&d)[25
     *reinterpret_cast<f32x2 *>(vs + 4 * (WS_TT * WS_BK)) = d[5 * i + 3];
 }
 
+// KiB i (0..31) of U image kc into Us[buf]
+__device__ __forceinline__ void ws_dma(const WsCtx &c, const WsUnit &u, int kc, int buf, int i)
+{
+    lds_dma_b128(u.rsU, c.dma_v, __builtin_amdgcn_readfirstlane(kc * (WS_UIMG * 4) + i * 1024),
+                 __builtin_amdgcn_readfirstlane(c.us_lds + (unsigned)(buf * WS_UIMG * 4 + i * 1024)));
+}
+
 // first staging of a unit: groups 0, 1, 2 load chunks 0, 1, 2 (transformed in the prologue, in step 0, in step 1), groups 2 and
 // 3 DMA U(0) into Us[0] (group 2 first, so that its wait for the DMA does not depend on the loads behind it)
 template <int Q>
 __device__ __forceinline__ void ws_first_loads(const WsCtx &c, const WsUnit &u, const unsigned (&vo)[25], f32x2 (&d)[25])
 {
     if (Q >= 2) {
-        const unsigned uv = Q == 2 ? c.uvoff0 : c.uvoff3, ul = Q == 2 ? c.us_lds0 : c.us_lds3;
 #pragma unroll
-        for (int i = 0; i < 8; i++) lds_dma_b128(u.rsU, uv, i * 1024, __builtin_amdgcn_readfirstlane(ul + (unsigned)(i * 1024)));
+        for (int i = 0; i < 8; i++) ws_dma(c, u, 0, 0, (Q == 2 ? 0 : 16) + 8 * c.wn + i);
     }
     if (Q <= 2) {
         const int kq = Q < c.KC ? Q : c.KC - 1;
@@ -175,12 +207,13 @@ __device__ __forceinline__ void ws_first_loads(const WsCtx &c, const WsUnit &u, 
 
 // K step kc (phase PH = kc mod 4) of a wave of group Q: one MFMA per slot, each closed by a full scheduling barrier so that
 // the staging work stays where it is written, a slot's worth at a time, in the shadow of the MFMAs.
-template <int Q, int PH>
+template <int PS, int WN, int PH>
 __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc, int &cur, f32x16 (&acc)[3], f32x4 (&af)[2], f32x4 (&bf)[2],
-                                         f32x2 (&d)[25], const unsigned (&vo)[25])
+                                         f32x2 (&d)[25], const unsigned (&vo)[25] WS_ST_ARG)
 {
-    constexpr int NP = ws_np(Q);
-    constexpr int ROLE = (Q - PH + 4) & 3;   // 3: load chunk kc+3, 2: DMA quarter 2+wn and transform chunk kc+2, 1: store chunk kc+1, 0: DMA quarter wn
+    constexpr int Q = ws_q(PS);
+    constexpr int NP = ws_np(PS);
+    constexpr int ROLE = (Q - PH + 4) & 3;   // 3: load chunk kc+3, 2: transform chunk kc+2, 1: store chunk kc+1 (+ U DMA), 0: U DMA only
     constexpr int SET0 = (PH * NP) & 1;      // operand register set of this step's first position
     const int kn1 = kc + 1 < c.KC ? kc + 1 : c.KC - 1;   // chunk indices past the end are clamped (staging nobody reads)
     const int kn3 = kc + 3 < c.KC ? kc + 3 : c.KC - 1;
@@ -191,15 +224,21 @@ __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc
             const int sl = 4 * n + j;
             const int set = (SET0 + n) & 1;
             if (n == NP - 1 && j == 0) {
-                if (!(WS_ABL & 1) && (ROLE == 0 || ROLE == 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the U DMA has landed
+                if (!(WS_ABL & 1) && WN == 0 && (ROLE == 0 || ROLE == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the U DMA has landed
+#ifdef WS_STAMPS
+                const unsigned t0 = (unsigned)__builtin_amdgcn_s_memtime();
                 __syncthreads();
+                st[PH] += (unsigned)__builtin_amdgcn_s_memtime() - t0;
+#else
+                __syncthreads();
+#endif
             }
             // operands of the next position (of the next step's first one, out of the other buffer, after the barrier)
             if (j < 2) {
                 const int nn = n + 1 < NP ? n + 1 : 0;
                 const int buf = n + 1 < NP ? cur : cur ^ 1;
-                const int p = 5 * ws_tab(Q, nn, 0) + ws_tab(Q, nn, 1);
-                const int um = 4 * ws_umap(ws_tab(Q, nn, 0)) + ws_umap(ws_tab(Q, nn, 1));
+                const int p = 5 * ws_tab(PS, nn, 0) + ws_tab(PS, nn, 1);
+                const int um = 4 * ws_umap(ws_tab(PS, nn, 0)) + ws_umap(ws_tab(PS, nn, 1));
                 if (j == 0) af[set ^ 1] = *reinterpret_cast<const f32x4 *>(c.Vs + buf * WS_VIMG + p * (WS_TT * WS_BK) + c.rd_v);
                 else bf[set ^ 1] = *reinterpret_cast<const f32x4 *>(c.Us + buf * WS_UIMG + um * (WS_BN * WS_BK) + c.rd_u);
             }
@@ -207,29 +246,28 @@ __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc
                 if (sl < 24) d[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u.rsA, vo[sl], 4 * kn3 * WS_BK, 0));
                 if (sl == 23) d[24] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u.rsA, vo[24], 4 * kn3 * WS_BK, 0));
             }
-            // B^T d B of chunk kc+2 already in the DMA step before its store step (its loads went out a step ago): the store
-            // step of a wave pair, whose non-MFMA work both waves of one SIMD do at the same time, is left with the stores
+            // B^T d B of chunk kc+2 in the step before its store step (its loads went out a step ago)
             if (ROLE == 2 && !(WS_ABL & 8)) {
                 if (sl == 14) ws_rows(d);
                 if (sl == 17) ws_cols(d);
             }
             if (ROLE == 1 && !(WS_ABL & 8) && sl >= 1 && sl <= 13 && (sl - 1) % 3 == 0) ws_store_row(c, d, cur ^ 1, (sl - 1) / 3);
-            if (!(WS_ABL & 2) && (ROLE == 0 || ROLE == 2) && sl >= 1 && sl <= 8) {   // U(kc+1): this wave's quarter, 1 KiB a slot
-                const unsigned uv = ROLE == 0 ? c.uvoff0 : c.uvoff3, ul = ROLE == 0 ? c.us_lds0 : c.us_lds3;
-                lds_dma_b128(u.rsU, uv, __builtin_amdgcn_readfirstlane(kn1 * (WS_UIMG * 4) + (sl - 1) * 1024),
-                             __builtin_amdgcn_readfirstlane(ul + (unsigned)((cur ^ 1) * WS_UIMG * 4 + (sl - 1) * 1024)));
-            }
-            acc[ws_tab(Q, n, 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][j], bf[set][j], acc[ws_tab(Q, n, 2)], 0, 0, 0);
+            // U(kc+1), 1 KiB a slot, by the waves of channel half 0 only (of the two waves of a SIMD the one with the lower id is
+            // served first, tools/ws_stamps.py: its staging work runs beside the other wave's MFMAs, the other wave's does not)
+            if (!(WS_ABL & 2) && WN == 0 && ((ROLE == 0 && sl < WS_DMA0) || (ROLE == 1 && sl < 32 - WS_DMA0)))
+                ws_dma(c, u, kn1, cur ^ 1, ROLE == 0 ? sl : WS_DMA0 + sl);
+            acc[ws_tab(PS, n, 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][j], bf[set][j], acc[ws_tab(PS, n, 2)], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     cur ^= 1;
 }
 
-template <int Q>
+template <int PS, int WN>
 __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_start, int x_count, int lidl, int per)
 {
-    const int lane = c.lane, li = lane & 31, half = lane >> 5, wn = c.wn;
+    constexpr int Q = ws_q(PS);
+    const int lane = c.lane, li = lane & 31, half = lane >> 5, wn = WN;
     f32x2 d[25];
     unsigned vo[25];
     f32x16 acc[3];
@@ -237,6 +275,9 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     WsUnit u;
     int tb = 0;
+#ifdef WS_STAMPS
+    unsigned st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     ws_setup(a, c, x_start + lidl, 0, Q == 0, u, vo);
     ws_first_loads<Q>(c, u, vo, d);
     for (;;) {
@@ -260,18 +301,25 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         if (Q == 2 || Q == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         {
-            constexpr int p = 5 * ws_tab(Q, 0, 0) + ws_tab(Q, 0, 1);
-            constexpr int um = 4 * ws_umap(ws_tab(Q, 0, 0)) + ws_umap(ws_tab(Q, 0, 1));
+            constexpr int p = 5 * ws_tab(PS, 0, 0) + ws_tab(PS, 0, 1);
+            constexpr int um = 4 * ws_umap(ws_tab(PS, 0, 0)) + ws_umap(ws_tab(PS, 0, 1));
             af[0] = *reinterpret_cast<const f32x4 *>(c.Vs + p * (WS_TT * WS_BK) + c.rd_v);
             bf[0] = *reinterpret_cast<const f32x4 *>(c.Us + um * (WS_BN * WS_BK) + c.rd_u);
         }
         int cur = 0;
+#ifdef WS_STAMPS
+        const unsigned tk0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
         for (int kc = 0; kc < c.KC; kc += 4) {   // KC % 4 == 0 (Cin % 32 == 0, host-checked)
-            ws_kstep<Q, 0>(c, u, kc, cur, acc, af, bf, d, vo);
-            ws_kstep<Q, 1>(c, u, kc + 1, cur, acc, af, bf, d, vo);
-            ws_kstep<Q, 2>(c, u, kc + 2, cur, acc, af, bf, d, vo);
-            ws_kstep<Q, 3>(c, u, kc + 3, cur, acc, af, bf, d, vo);
+            ws_kstep<PS, WN, 0>(c, u, kc, cur, acc, af, bf, d, vo WS_ST_PASS);
+            ws_kstep<PS, WN, 1>(c, u, kc + 1, cur, acc, af, bf, d, vo WS_ST_PASS);
+            ws_kstep<PS, WN, 2>(c, u, kc + 2, cur, acc, af, bf, d, vo WS_ST_PASS);
+            ws_kstep<PS, WN, 3>(c, u, kc + 3, cur, acc, af, bf, d, vo WS_ST_PASS);
         }
+#ifdef WS_STAMPS
+        st[6] += (unsigned)__builtin_amdgcn_s_memtime() - tk0;
+        st[7] += c.KC;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads / DMA have landed
         f32x4 bv4 = {bv, bv, bv, bv};
         asm volatile("" : "+v"(bv4));   // hipcc's own wait for the bias load goes here, where nothing is in flight
@@ -295,7 +343,7 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
 #pragma unroll
         for (int e4 = 0; e4 < 4; e4++) {
             exs[((wn * 4 + Q) * 4 + e4) * 64 + lane] = f32x4{acc[1][4 * e4], acc[1][4 * e4 + 1], acc[1][4 * e4 + 2], acc[1][4 * e4 + 3]};
-            if (Q == 3) exc[(wn * 4 + e4) * 64 + lane] = f32x4{acc[2][4 * e4], acc[2][4 * e4 + 1], acc[2][4 * e4 + 2], acc[2][4 * e4 + 3]};
+            if (PS == 3 || PS == 4) exc[(wn * 4 + e4) * 64 + lane] = f32x4{acc[2][4 * e4], acc[2][4 * e4 + 1], acc[2][4 * e4 + 2], acc[2][4 * e4 + 3]};
         }
         __syncthreads();
         constexpr int IMP = Q == 0 ? 2 : Q == 1 ? 0 : Q == 2 ? 3 : 1;   // whose slot 1 this wave needs: S10, S01, S21, S12
@@ -325,6 +373,10 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         tb ^= 1;
         lidl = nl;
     }
+#ifdef WS_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; i++) ws_stamps[wn * 4 + Q][i] += st[i];
+#endif
 }
 
 // in [B][H][W][Cin]; up = packed U (ws_pack_u); out [B][Ho][Wo][Cout] = relu(conv_stride2 + bias).
@@ -348,12 +400,8 @@ __global__ __launch_bounds__(512) void wino_s2_fused(WsArgs a, int n_units)
     c.KC = a.Cin / WS_BK;
     c.lane = lane;
     c.wn = wn;
-    // a DMA wave copies a quarter (8 KiB) of a U image: quarter wn in role 0, quarter 2 + wn in role 2
-    const unsigned us_base = (unsigned)(unsigned long long)c.Us;
-    c.uvoff0 = (unsigned)(wn * 8192 + lane * 16);
-    c.uvoff3 = (unsigned)((2 + wn) * 8192 + lane * 16);
-    c.us_lds0 = __builtin_amdgcn_readfirstlane(us_base + (unsigned)(wn * 8192));
-    c.us_lds3 = __builtin_amdgcn_readfirstlane(us_base + (unsigned)((2 + wn) * 8192));
+    c.dma_v = (unsigned)(lane * 16);
+    c.us_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)c.Us);
     // LDS row = 8 channels of one tile (or output channel) = two 16-B halves; rows 16..31 of every 32 keep their halves
     // swapped (wf_pack_u stores U the same way): the four 16-lane groups of a ds_read_b128 are conflict-free
     c.st_off = c.t_ld * WS_BK + (((c.cp >> 1) ^ ((c.t_ld >> 4) & 1)) * 4) + (c.cp & 1) * 2;
@@ -370,10 +418,17 @@ __global__ __launch_bounds__(512) void wino_s2_fused(WsArgs a, int n_units)
     const int lidl = blockIdx.x >> 3;
     if (lidl >= x_count) return;                // whole workgroup: nothing to do
 
-    if (q == 0) ws_run<0>(a, c, x_start, x_count, lidl, per);
-    else if (q == 1) ws_run<1>(a, c, x_start, x_count, lidl, per);
-    else if (q == 2) ws_run<2>(a, c, x_start, x_count, lidl, per);
-    else ws_run<3>(a, c, x_start, x_count, lidl, per);
+    if (wn == 0) {
+        if (q == 0) ws_run<0, 0>(a, c, x_start, x_count, lidl, per);
+        else if (q == 1) ws_run<1, 0>(a, c, x_start, x_count, lidl, per);
+        else if (q == 2) ws_run<2, 0>(a, c, x_start, x_count, lidl, per);
+        else ws_run<3, 0>(a, c, x_start, x_count, lidl, per);
+    } else {
+        if (q == 0) ws_run<4, 1>(a, c, x_start, x_count, lidl, per);
+        else if (q == 1) ws_run<1, 1>(a, c, x_start, x_count, lidl, per);
+        else if (q == 2) ws_run<2, 1>(a, c, x_start, x_count, lidl, per);
+        else ws_run<5, 1>(a, c, x_start, x_count, lidl, per);
+    }
 }
 
 // Host: g [Cout][Cin][3][3] (OIHW, BN folded) -> packed U for wino_s2_fused, in wf_pack_u's image order:
