@@ -1666,11 +1666,16 @@ int apr_profile_read(apr_engine *e, apr_profile_slot *slots, int *n_slots)
 
 }  // extern "C"
 
-#ifdef WS_STAMPS   // developer build (tools/ws_stamps.py)
+#if defined(WS_STAMPS) || defined(W8_STAMPS)   // developer builds (tools/ws_stamps.py): 64 counters of workgroup 0 of the stamped kernel
 extern "C" int apr_debug_ws_stamps(unsigned long long *dst, int reset)
 {
     static const unsigned long long zero[64] = {};
+#ifdef WS_STAMPS
     if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(apr::ws_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(apr::ws_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+#else
+    if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(apr::w8_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(apr::w8_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+#endif
 }
 #endif

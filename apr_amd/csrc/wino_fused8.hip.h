@@ -25,6 +25,11 @@ namespace apr {
 #define W8_ABL 0   // developer timing ablations (tools/wino_fused_bench.cpp): 1 no patch loads, 2 no transform/stores, 4 no U DMA, 8 no barrier
 #endif
 
+#ifdef W8_STAMPS   // developer build (tools/ws_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles waited at the barrier of
+                   // its load steps [0] / store steps [1], K loop total [6], steps [7]
+__device__ unsigned long long w8_stamps[8][8];
+#endif
+
 constexpr int WF8_LDS_BYTES = 2 * 2 * WF_POS * 4 + 2 * WF_TT * 16;   // Vs[2], Us[2], two tile tables
 
 // grid of the persistent kernel: one workgroup per CU, a multiple of 8 (one share per XCD), no more than the units need
@@ -47,6 +52,16 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
     const int phs = __builtin_amdgcn_readfirstlane(wave & 1);    // ph as a scalar: the epilogue branches on it instead of selecting per lane
+    // Waves w and w + 4 share a SIMD, and the SIMD serves the older one (w < 4) first: its staging instructions run beside
+    // the other wave's MFMAs, the other wave's own are exposed (wino_s2_fused.hip.h, tools/ws_stamps.py).  The U DMA is
+    // therefore the work of waves 0-3 alone, a quarter of the image each in every step.
+    // Stamps of the K step (-DW8_STAMPS, tools/ws_stamps.py): 4.8 k cycles against 4.1 k of MFMA issue.  The SIMDs of the
+    // step's store role are busy throughout: 48 MFMAs up to the barrier + 64 v_pk_add_f32 + 32 ds_write_b64 (their
+    // VGPR transfer) + the DMA issue = 3.65 k cycles against 2.0-2.3 k on the SIMDs of the load role, which then wait at the
+    // barrier: fp32 VALU and LDS stores take MFMA issue time one for one.  Measured and dropped: opposite roles on the two
+    // waves of a SIMD (the transform work spread over all four SIMDs): the load-role wave takes the matrix pipe first, the
+    // store-role wave runs after it, 1 % slower; with s_setprio 2 on the store-role wave: equal to this form.
+    const int dma_wave = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0);
     const int ph = wave & 1;                    // which 8 of the 16 positions; also the staging parity
     const int sub = wave >> 1;                  // the pair: 2 (tiles) x 2 (channels)
     const int wm = sub >> 1, wn = sub & 1;
@@ -110,18 +125,18 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     i32x4 rsU;
     rsU.z = 0x7FFFFFFF;
     rsU.w = 0x00020000;
-    const unsigned us_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(Us + sub * (WF_POS / 4)));
-    const unsigned uvoff = (unsigned)(sub * (WF_POS / 4) * 4 + lane * 16);
+    const unsigned us_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(Us + (wave & 3) * (WF_POS / 4)));
+    const unsigned uvoff = (unsigned)((wave & 3) * (WF_POS / 4) * 4 + lane * 16);
 
     f32x2 d[16];
     unsigned vo[16];
 #define W8_OFFSETS(VOFF_, VMASK_)                                                                        \
     _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++)                                                 \
         vo[ij_] = (((VMASK_) >> ij_) & 1u) ? (VOFF_) + 4u * (unsigned)(((ij_ >> 2) * W + (ij_ & 3)) * Cin) : OOB;
-    // first staging of a unit: parity 0 DMAs U chunk 0 into Us[0], every parity loads its first V chunk (0 / 1)
+    // first staging of a unit: waves 0-3 DMA U chunk 0 into Us[0], every parity loads its first V chunk (0 / 1)
 #define W8_FIRST_LOADS()                                                                                 \
     {                                                                                                    \
-        if (ph == 0) {                                                                                   \
+        if (dma_wave) {                                                                                  \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) W8_DMA_U1(0, 0, i_)                         \
         }                                                                                                \
         _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++) W8_LOAD_V1(phs, ij_)  /* KC >= 2 */          \
@@ -148,7 +163,10 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     const int st_off = t_ld * WF_BK + (((cp >> 1) ^ ((t_ld >> 4) & 1)) * 4) + (cp & 1) * 2;
     const int rd_sw = (half ^ ((li >> 4) & 1)) * 4;
     const int rd_v = (ph * 8) * (64 * WF_BK) + (wm * 32 + li) * WF_BK + rd_sw;   // this wave's first position
-    const int rd_u = (ph * 8) * (64 * WF_BK) + (wn * 32 + li) * WF_BK + rd_sw;
+    // one base register for all operand addresses of U: hidden from the optimiser, which otherwise keeps one register per
+    // address (the constants past 64 KiB do not fit the instruction's offset field once folded with the image's own offset)
+    unsigned rd_ub = (unsigned)((2 * WF_POS + (ph * 8) * (64 * WF_BK) + (wn * 32 + li) * WF_BK + rd_sw) * 4);
+    asm volatile("" : "+v"(rd_ub));
 
     f32x16 acc[8];
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -158,18 +176,42 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         if (((Q_) & 1) == 0)                                                                             \
             af[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(Vs + (BUF_) * WF_POS + rd_v + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)); \
         else                                                                                             \
-            bf[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(Us + (BUF_) * WF_POS + rd_u + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)); \
+            bf[SET_][(Q_) >> 1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(wf_smem) + rd_ub + ((BUF_) * WF_POS + (2 * (G_) + ((Q_) >> 1)) * (64 * WF_BK)) * 4); \
     }
 
     // K step: 32 slots of one MFMA (4 groups g of two positions x 4 k-pairs), each closed by a full
     // scheduling barrier.  Slots 0-3 of a group read the next group's operands (g = 3: after the
     // barrier, the next step's first group).
-    //   ROLE 0 (load):   chunk kc+2 -> d, one buffer load per slot in groups 0-1
-    //   ROLE 1 (store):  slot 0 row transform of d (chunk kc+1, loaded in the previous step); groups 0-1 the
-    //                    U(kc+1) DMA, one piece per slot from slot 1; groups 1-2 the column transform + LDS
-    //                    store, one row (four positions) per fourth slot; before the barrier vmcnt(0)
+    //   ROLE 0 (load):   chunk kc+2 -> d, one buffer load per slot in groups 0-1; a DMA wave: a piece of its quarter
+    //                    of U(kc+1) ahead of the load of every even slot; before the barrier vmcnt(2): the two loads
+    //                    behind the last piece may still be in flight
+    //   ROLE 1 (store):  slot 0 row transform of d (chunk kc+1, loaded in the previous step); groups 0-1 of a DMA
+    //                    wave: its quarter of U(kc+1), one piece per slot from slot 1; groups 1-2 the column
+    //                    transform + LDS store, one row (four positions) per fourth slot; before the barrier vmcnt(0)
     // Chunk indices past the end are clamped (staging nobody reads).
-#define W8_KSTEP(ROLE, FIRST)                                                                                 \
+#ifdef W8_STAMPS
+#define W8_BAR_STAMPED(ROLE)                                                                             \
+    {                                                                                                    \
+        const unsigned t0_ = (unsigned)__builtin_amdgcn_s_memtime();                                     \
+        __syncthreads();                                                                                 \
+        st8[ROLE] += (unsigned)__builtin_amdgcn_s_memtime() - t0_;                                       \
+    }
+    unsigned st8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned ts0 = 0, ts1 = 0, ts2 = 0;
+#define W8_LOADWAIT_STAMPED(ROLE, SL)                                                                    \
+    if ((SL) == 0) ts0 = (unsigned)__builtin_amdgcn_s_memtime();                                         \
+    if ((SL) == 1) ts1 = (unsigned)__builtin_amdgcn_s_memtime();                                         \
+    if ((SL) == 10) ts2 = (unsigned)__builtin_amdgcn_s_memtime();                                        \
+    if ((SL) == 23) {                                                                                    \
+        const unsigned ts3 = (unsigned)__builtin_amdgcn_s_memtime();                                     \
+        if (ROLE == 1) { st8[2] += ts1 - ts0; st8[3] += ts2 - ts1; st8[4] += ts3 - ts2; }                \
+        else st8[5] += ts3 - ts0;                                                                        \
+    }
+#else
+#define W8_LOADWAIT_STAMPED(ROLE, SL)
+#define W8_BAR_STAMPED(ROLE) if (!(W8_ABL & 8)) __syncthreads();
+#endif
+#define W8_KSTEP(ROLE, FIRST)                                                                            \
     {                                                                                                    \
         const int kn1 = kc + 1 < KC ? kc + 1 : KC - 1;                                                   \
         const int kn2 = kc + 2 < KC ? kc + 2 : KC - 1;                                                   \
@@ -179,16 +221,19 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
             {                                                                                            \
                 const int sl = 8 * g + i;                                                                \
                 if (g == 3 && i == 0) {                                                                  \
-                    if (ROLE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-                    if (!(W8_ABL & 8)) __syncthreads();                                                  \
+                    if (dma_wave && ROLE == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              \
+                    if (dma_wave && ROLE == 0 && !(W8_ABL & 5)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
+                    W8_BAR_STAMPED(ROLE)                                                                 \
                 }                                                                                        \
                 if (i < 4) {                                                                             \
                     if (g < 3) W8_READ_OP((g + 1) & 1, cur, g + 1, i)                                    \
                     else W8_READ_OP(0, cur ^ 1, 0, i)                                                    \
                 }                                                                                        \
+                if (!(W8_ABL & 4) && dma_wave && ROLE == 0 && sl < 16 && (sl & 1) == 0) W8_DMA_U1(kn1, cur ^ 1, sl >> 1) \
                 if (!(W8_ABL & 1) && ROLE == 0 && sl < 16) W8_LOAD_V1(kn2, sl)                           \
+                W8_LOADWAIT_STAMPED(ROLE, sl)                                                            \
                 if (!(W8_ABL & 2) && ROLE == 1 && sl == 0) W8_ROWS()                                     \
-                if (!(W8_ABL & 4) && ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(kn1, cur ^ 1, sl - 1)    \
+                if (!(W8_ABL & 4) && dma_wave && ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(kn1, cur ^ 1, sl - 1) \
                 if (!(W8_ABL & 2) && ROLE == 1 && sl >= 10 && sl <= 22 && ((sl - 10) & 3) == 0) {        \
                     _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) W8_STORE_POS(cur ^ 1, (sl - 10) >> 2, q_) \
                 }                                                                                        \
@@ -223,16 +268,19 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the U DMA has landed
         }
+        if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the U DMA has landed (parity 1: and chunk 1, which its step 0 transforms at once)
         __syncthreads();
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) W8_READ_OP(0, 0, 0, qq)
 
         WF_STAMP(2)
         int cur = 0;
+#ifdef W8_STAMPS
+        const unsigned tk0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
         // the first step's first MFMA of every accumulator takes C = 0: no clearing pass (128 v_mov a wave)
-        if (ph == 0) {
+        if (phs == 0) {
             {
                 int kc = 0;
                 W8_KSTEP(0, true)
@@ -259,6 +307,10 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
                 kc--;
             }
         }
+#ifdef W8_STAMPS
+        st8[6] += (unsigned)__builtin_amdgcn_s_memtime() - tk0;
+        st8[7] += KC;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         f32x2 bv2 = {bv, bv};
         asm volatile("" : "+v"(bv2));   // hipcc's own wait for the bias load goes here, where nothing is in flight
@@ -333,7 +385,13 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         __syncthreads();    // every wave has read its half of the exchange: Vs may be staged again
         bn = bn_n; b0 = b0_n; tb ^= 1; lidl = nl;
     }
+#ifdef W8_STAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; i++) w8_stamps[wave][i] += st8[i];
+#endif
 #undef W8_KSTEP
+#undef W8_BAR_STAMPED
+#undef W8_LOADWAIT_STAMPED
 #undef W8_READ_OP
 #undef W8_LOAD_V1
 #undef W8_DMA_U1

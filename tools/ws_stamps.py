@@ -1,7 +1,7 @@
-"""Developer tool: per-wave s_memtime stamps of wino_s2_fused (a -DWS_STAMPS side build, tools/build_variant.sh):
-    APR_AMD_LIB=tools/tmp_libs/libapr_NAME.so python tools/ws_stamps.py [layer ...]
-Runs one 2048-window pass per listed stride-2 layer alone (all others excluded through the min-Cin / min-px knobs is not
-possible, so the stamps of a full pass are the sum over the fused stride-2 layers; use APR_WINO_S2_FUSED_MIN_CIN to cut)."""
+"""Developer tool: per-wave s_memtime stamps of wino_s2_fused (a -DWS_STAMPS side build, tools/build_variant.sh) or of
+wino_fused8_f2 (-DW8_STAMPS; WS_PHASES=2: load steps / store steps):
+    APR_AMD_LIB=tools/tmp_libs/libapr_NAME.so [WS_PHASES=2] python tools/ws_stamps.py
+One 2048-window pass; the counters of workgroup 0 are summed over the layers that run the stamped kernel."""
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, '.')
