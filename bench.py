@@ -483,7 +483,11 @@ def parity_report(ref, probs, label, match, C):
 
 def leg_host_sweep(model, eng, pcm_head, args, empty):
     """PCIe-inclusive rate (never `value`): apr_sweep_files over recordings in pageable host memory."""
-    files = [pcm_head] + [model.synth_pcm(0, 100 + f, args.seconds) for f in range(11)]
+    # 30 recordings = 9 passes of 2048 windows: the first pass's staging copy has nothing to hide behind (12 recordings = 4 passes
+    # read 8.9 audio-hours/s for that reason alone); a directory sweep is far longer still
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as pool:
+        files = [pcm_head] + list(pool.map(lambda f: model.synth_pcm(0, 100 + f, args.seconds), range(29)))
     eng.sweep_files(files[:2], trust=TRUST, empty_class=empty)           # allocates the staging buffers
     t1 = time.perf_counter()
     res = eng.sweep_files(files, trust=TRUST, empty_class=empty)
