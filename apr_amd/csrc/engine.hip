@@ -1514,17 +1514,48 @@ static int sweep_files_on(apr_engine *e, const int *idx, int n_idx, const uint8_
         const Seg &last = ps.back();
         const size_t n_stream = last.base_w + last.nw;                  // stream windows computed in this pass
         const size_t bytes = (n_stream - 1) * stride_bytes + APR_SAMPLE_SIZE;
+        // pageable -> pinned staging, cut into pieces for a few host threads (one thread copies 8-10 GB/s: 20-25 ms for a pass of 2048
+        // windows, which the first pass of a sweep cannot hide behind anything)
+        struct Piece { uint8_t *dst; const uint8_t *src; size_t n; };   // src == nullptr: zero fill
+        std::vector<Piece> pieces;
+        auto add_piece = [&](uint8_t *dst, const uint8_t *src, size_t n) {
+            const size_t kPiece = (size_t)16 << 20;
+            for (size_t o = 0; o < n; o += kPiece) pieces.push_back({dst + o, src ? src + o : nullptr, std::min(kPiece, n - o)});
+        };
         size_t cur = 0;
         for (const Seg &sg : ps) {
             const size_t base = sg.base_w * stride_bytes;
-            if (base > cur) memset(e->h_pin[b] + cur, 0, base - cur);
+            if (base > cur) add_piece(e->h_pin[b] + cur, nullptr, base - cur);
             const size_t src0 = sg.w0 * stride_bytes;
             const size_t want = (sg.nw - 1) * stride_bytes + APR_SAMPLE_SIZE;
             const size_t have = std::min(want, nbytes[sg.file] - src0);
-            memcpy(e->h_pin[b] + base, pcm[sg.file] + src0, have);
+            add_piece(e->h_pin[b] + base, pcm[sg.file] + src0, have);
             cur = base + have;
         }
-        if (bytes > cur) memset(e->h_pin[b] + cur, 0, bytes - cur);
+        if (bytes > cur) add_piece(e->h_pin[b] + cur, nullptr, bytes - cur);
+        {
+            auto work = [&pieces](size_t first, size_t step) {
+                for (size_t i = first; i < pieces.size(); i += step) {
+                    if (pieces[i].src) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n);
+                    else memset(pieces[i].dst, 0, pieces[i].n);
+                }
+            };
+            const size_t n_thr = std::min<size_t>(4, pieces.size());
+            std::vector<std::thread> helpers;
+            try {
+                for (size_t t = 1; t < n_thr; t++) helpers.emplace_back(work, t, n_thr);
+            } catch (const std::exception &) {}   // no more threads to be had: the caller's thread copies what is left
+            const size_t started = helpers.size() + 1;
+            if (started == n_thr) work(0, n_thr);
+            else {   // pieces of the threads that did not start
+                for (size_t i = 0; i < pieces.size(); i++)
+                    if (i % n_thr == 0 || i % n_thr >= started) {
+                        if (pieces[i].src) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n);
+                        else memset(pieces[i].dst, 0, pieces[i].n);
+                    }
+            }
+            for (std::thread &t : helpers) t.join();
+        }
         HIPCHK(e, hipMemcpyAsync(e->d_pin[b], e->h_pin[b], bytes, hipMemcpyHostToDevice, e->copy_stream));
         HIPCHK(e, hipEventRecord(e->ev_h2d[b], e->copy_stream));
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
