@@ -1267,6 +1267,31 @@ int apr_score(apr_engine *e, const uint8_t *pcm, size_t total_bytes, size_t n_wi
 }
 
 
+// Host copies into pinned staging, cut into pieces and spread over up to four threads (the caller's included).
+struct CopyPiece { uint8_t *dst; const uint8_t *src; size_t n; };   // src == nullptr: zero fill
+static void add_pieces(std::vector<CopyPiece> &pieces, uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t kPiece = (size_t)4 << 20;
+    for (size_t o = 0; o < n; o += kPiece) pieces.push_back({dst + o, src ? src + o : nullptr, std::min(kPiece, n - o)});
+}
+static void run_pieces(const std::vector<CopyPiece> &pieces)
+{
+    auto one = [&pieces](size_t i) {
+        if (pieces[i].src) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n);
+        else memset(pieces[i].dst, 0, pieces[i].n);
+    };
+    const size_t n_thr = std::min<size_t>(4, pieces.size());
+    std::vector<std::thread> helpers;
+    try {
+        for (size_t t = 1; t < n_thr; t++)
+            helpers.emplace_back([&one, &pieces, t, n_thr] { for (size_t i = t; i < pieces.size(); i += n_thr) one(i); });
+    } catch (const std::exception &) {}   // no more threads to be had: the caller's thread copies what is left
+    const size_t started = helpers.size() + 1;
+    for (size_t i = 0; i < pieces.size(); i++)
+        if (i % n_thr == 0 || i % n_thr >= started) one(i);
+    for (std::thread &t : helpers) t.join();
+}
+
 // ---- live mode: one new second per stream and tick (src/daemon/daemon.go:104-125) ----
 static int ring_reserve(apr_engine *e, int n_streams)
 {
@@ -1316,7 +1341,15 @@ int apr_stream_tick(apr_engine *e, const uint8_t *segments, int n_streams, doubl
     const bool primed = e->ring_n == n_streams;
     if (primed)   // previous <- new of the last tick (the halves of a row do not overlap)
         HIPCHK(e, hipMemcpy2DAsync(e->d_ring, win, e->d_ring + seg, win, seg, (size_t)n_streams, hipMemcpyDeviceToDevice, e->stream));
-    if (!own) memcpy(e->h_ring, segments, (size_t)n_streams * seg);
+    if (!own) {   // 24.6 MB at 256 streams: 1.3 ms of the tick on one thread
+        try {
+            std::vector<CopyPiece> pieces;
+            add_pieces(pieces, e->h_ring, segments, (size_t)n_streams * seg);
+            run_pieces(pieces);
+        } catch (const std::exception &) {
+            memcpy(e->h_ring, segments, (size_t)n_streams * seg);
+        }
+    }
     HIPCHK(e, hipMemcpy2DAsync(e->d_ring + seg, win, e->h_ring, seg, seg, (size_t)n_streams, hipMemcpyHostToDevice, e->stream));
     if (!primed) {   // the first segment of a stream has no predecessor: nothing to score yet (daemon.go:115-119)
         HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1514,48 +1547,21 @@ static int sweep_files_on(apr_engine *e, const int *idx, int n_idx, const uint8_
         const Seg &last = ps.back();
         const size_t n_stream = last.base_w + last.nw;                  // stream windows computed in this pass
         const size_t bytes = (n_stream - 1) * stride_bytes + APR_SAMPLE_SIZE;
-        // pageable -> pinned staging, cut into pieces for a few host threads (one thread copies 8-10 GB/s: 20-25 ms for a pass of 2048
-        // windows, which the first pass of a sweep cannot hide behind anything)
-        struct Piece { uint8_t *dst; const uint8_t *src; size_t n; };   // src == nullptr: zero fill
-        std::vector<Piece> pieces;
-        auto add_piece = [&](uint8_t *dst, const uint8_t *src, size_t n) {
-            const size_t kPiece = (size_t)16 << 20;
-            for (size_t o = 0; o < n; o += kPiece) pieces.push_back({dst + o, src ? src + o : nullptr, std::min(kPiece, n - o)});
-        };
+        // pageable -> pinned staging on a few host threads (one thread copies 8-10 GB/s: 20-25 ms for a pass of 2048 windows,
+        // which the first pass of a sweep cannot hide behind anything)
+        std::vector<CopyPiece> pieces;
         size_t cur = 0;
         for (const Seg &sg : ps) {
             const size_t base = sg.base_w * stride_bytes;
-            if (base > cur) add_piece(e->h_pin[b] + cur, nullptr, base - cur);
+            if (base > cur) add_pieces(pieces, e->h_pin[b] + cur, nullptr, base - cur);
             const size_t src0 = sg.w0 * stride_bytes;
             const size_t want = (sg.nw - 1) * stride_bytes + APR_SAMPLE_SIZE;
             const size_t have = std::min(want, nbytes[sg.file] - src0);
-            add_piece(e->h_pin[b] + base, pcm[sg.file] + src0, have);
+            add_pieces(pieces, e->h_pin[b] + base, pcm[sg.file] + src0, have);
             cur = base + have;
         }
-        if (bytes > cur) add_piece(e->h_pin[b] + cur, nullptr, bytes - cur);
-        {
-            auto work = [&pieces](size_t first, size_t step) {
-                for (size_t i = first; i < pieces.size(); i += step) {
-                    if (pieces[i].src) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n);
-                    else memset(pieces[i].dst, 0, pieces[i].n);
-                }
-            };
-            const size_t n_thr = std::min<size_t>(4, pieces.size());
-            std::vector<std::thread> helpers;
-            try {
-                for (size_t t = 1; t < n_thr; t++) helpers.emplace_back(work, t, n_thr);
-            } catch (const std::exception &) {}   // no more threads to be had: the caller's thread copies what is left
-            const size_t started = helpers.size() + 1;
-            if (started == n_thr) work(0, n_thr);
-            else {   // pieces of the threads that did not start
-                for (size_t i = 0; i < pieces.size(); i++)
-                    if (i % n_thr == 0 || i % n_thr >= started) {
-                        if (pieces[i].src) memcpy(pieces[i].dst, pieces[i].src, pieces[i].n);
-                        else memset(pieces[i].dst, 0, pieces[i].n);
-                    }
-            }
-            for (std::thread &t : helpers) t.join();
-        }
+        if (bytes > cur) add_pieces(pieces, e->h_pin[b] + cur, nullptr, bytes - cur);
+        run_pieces(pieces);
         HIPCHK(e, hipMemcpyAsync(e->d_pin[b], e->h_pin[b], bytes, hipMemcpyHostToDevice, e->copy_stream));
         HIPCHK(e, hipEventRecord(e->ev_h2d[b], e->copy_stream));
         HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_h2d[b], 0));
