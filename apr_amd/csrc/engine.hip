@@ -69,6 +69,7 @@ struct Layer {
     int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2),
                             // 4 = stride 2 in polyphase Winograd F(2,2) form (wino_s2.hip.h: 25 GEMMs + output transform),
                             // 5 = the same in one kernel (wino_s2_fused.hip.h)
+    int gn = 0;             // wino == 3 (8 waves), 5: N tiles per group in the unit order (wf_unit); 0 = all
     int fused_waves = 8;    // wino == 3: wino_fused8_f2 (8 waves a block) or wino_fused_f2 (4)
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
     int th = 0, tw = 0;     // 2x2-output tiles per window
@@ -418,6 +419,10 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
             const char *wv = getenv("APR_WINO_FUSED_WAVES");   // developer knob: 4 = the four-wave kernel
             L.wino = 3;
+            // unit order (wf_unit): N tiles in groups of four.  HBM fetch of a 2048-window pass, all N tiles of an M tile side by
+            // side -> groups of four: layer 7 7.9 -> 4.9 GB, layer 9 3.7 -> 2.4, layer 11 3.3 -> 1.2 (groups of two: the same;
+            // of one: 7.3 / 3.6 / 1.8 and twice the input on the layers of few N tiles); the times do not move (tools/gn_sweep.sh)
+            L.gn = getenv("APR_WINO_GN") ? atoi(getenv("APR_WINO_GN")) : 4;
             L.fused_waves = wv && atoi(wv) == 4 ? 4 : 8;
             L.ksplit = 1;
             L.th = (L.hout + 1) / 2;
@@ -471,6 +476,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
                 ws_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
                 if ((rc = dev_upload(e, &L.d_u, u))) return rc;
                 L.wino = 5;
+                L.gn = getenv("APR_WINO_S2_GN") ? atoi(getenv("APR_WINO_S2_GN")) : 4;   // layer 12: 4.5 -> 1.9 GB, layer 10: 2.0 -> 1.6
                 L.ksplit = 1;
                 L.th = (L.hout + 1) / 2;
                 L.tw = (L.wout + 1) / 2;
@@ -645,7 +651,7 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
                                    out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
             else
                 hipLaunchKernelGGL(wino_fused8_f2, dim3(wf8_grid((int)(tiles_m * tiles_n), e->n_cus)), dim3(512), WF8_LDS_BYTES, e->stream, in, L.d_u,
-                                   L.d_b, out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw), (int)(tiles_m * tiles_n));
+                                   L.d_b, out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw, tiles_m, L.gn), (int)(tiles_m * tiles_n));
             in = out;
             continue;
         }
@@ -658,7 +664,7 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             wa.in = in; wa.up = L.d_u; wa.bias = L.d_b; wa.out = out;
             wa.H = L.hin; wa.W = L.win; wa.Cin = L.cin; wa.Ho = L.hout; wa.Wo = L.wout; wa.Cout = L.cout;
             wa.th = L.th; wa.tw = L.tw; wa.T = (int)T; wa.tiles_n = tiles_n;
-            wa.mg = wf_magic(tiles_n, L.th, L.tw);
+            wa.mg = wf_magic(tiles_n, L.th, L.tw, tiles_m, L.gn);
             const int n_units = (int)(tiles_m * tiles_n);
             hipLaunchKernelGGL(wino_s2_fused, dim3(wf8_grid(n_units, e->n_cus)), dim3(512), WS_LDS_BYTES, e->stream, wa, n_units);
             in = out;

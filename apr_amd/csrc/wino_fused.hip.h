@@ -110,12 +110,29 @@ __device__ unsigned long long wf_stamps[4096][8];
 
 // Division by the launch's small constants without the ~30-instruction expansion per quotient:
 // q = (n * ceil(2^40 / d)) >> 40, exact while q < 2^24 and n < 2^31 (host: wf_magic).
-struct WfMagic { unsigned long long tiles_n, tpw, tw, th; };
+struct WfMagic {
+    unsigned long long tiles_n, tpw, tw, th;
+    unsigned long long upg_m, gn_m;   // the persistent kernels' unit order (wf_unit): units per N group, N tiles per group
+    int upg, gn;
+};
 __device__ __forceinline__ int wf_div(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
-inline WfMagic wf_magic(int tiles_n, int th, int tw)
+// Unit order of the persistent kernels: N tiles in groups of gn; within a group the units of one M tile follow each other, so
+// the workgroups of an XCD, which walk consecutive units, hold per / gn M tiles x gn N tiles at a time -- gn trades re-reads of the
+// input (once per group) against re-reads of U (once per per / gn concurrent units of an N tile).  gn = tiles_n: unit = bm * tiles_n + bn.
+__device__ __forceinline__ void wf_unit(int lid, const WfMagic &mg, int &bm, int &bn)
+{
+    const int grp = wf_div(lid, mg.upg_m);
+    const int r = lid - grp * mg.upg;
+    bm = wf_div(r, mg.gn_m);
+    bn = grp * mg.gn + (r - bm * mg.gn);
+}
+inline WfMagic wf_magic(int tiles_n, int th, int tw, long long tiles_m = 1, int gn = 0)
 {
     auto mk = [](long long d) { return (unsigned long long)(((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d); };
-    return WfMagic{mk(tiles_n), mk((long long)th * tw), mk(tw), mk(th)};
+    if (gn < 1 || gn > tiles_n) gn = tiles_n;
+    while (tiles_n % gn) gn--;           // a divisor of tiles_n
+    const long long upg = tiles_m * gn;
+    return WfMagic{mk(tiles_n), mk((long long)th * tw), mk(tw), mk(th), mk(upg), mk(gn), (int)upg, gn};
 }
 
 // in  [B][H][W][Cin] ; up = packed U (wf_pack_u) ; out [B][H][W][Cout] = relu(conv + bias)

@@ -84,8 +84,8 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     // tile table TB_ (zero padding = out-of-range buffer offsets)
 #define W8_SETUP(LID_, TB_, BN_, B0_, VOFF_, VMASK_)                                                     \
     {                                                                                                    \
-        const int bm_ = wf_div((LID_), mg.tiles_n);                                                      \
-        BN_ = (LID_) - bm_ * tiles_n;                                                                    \
+        int bm_;                                                                                         \
+        wf_unit((LID_), mg, bm_, BN_);                                                                   \
         const int g0_ = bm_ * WF_TT;                                                                     \
         B0_ = wf_div(g0_, mg.tpw);                                                                       \
         VOFF_ = OOB; VMASK_ = 0;                                                                         \

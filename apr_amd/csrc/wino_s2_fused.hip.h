@@ -110,8 +110,8 @@ struct WsUnit {   // what changes from unit to unit
 __device__ __forceinline__ void ws_setup(const WsArgs &a, const WsCtx &c, int lid, int tb, bool write_tbl, WsUnit &u, unsigned (&vo)[25])
 {
     constexpr unsigned OOB = 0x80000000u;
-    const int bm = wf_div(lid, a.mg.tiles_n);
-    u.bn = lid - bm * a.tiles_n;
+    int bm;
+    wf_unit(lid, a.mg, bm, u.bn);
     const int g0 = bm * WS_TT;                   // first tile of the unit (< T)
     u.b0 = wf_div(g0, a.mg.tpw);                 // its window
     unsigned voff = OOB, vmask = 0;
