@@ -115,11 +115,11 @@ struct WfMagic {
     unsigned long long upg_m, gn_m;   // the persistent kernels' unit order (wf_unit): units per N group, N tiles per group
     int upg, gn;
 };
-__device__ __forceinline__ int wf_div(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
+__host__ __device__ __forceinline__ int wf_div(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
 // Unit order of the persistent kernels: N tiles in groups of gn; within a group the units of one M tile follow each other, so
 // the workgroups of an XCD, which walk consecutive units, hold per / gn M tiles x gn N tiles at a time -- gn trades re-reads of the
 // input (once per group) against re-reads of U (once per per / gn concurrent units of an N tile).  gn = tiles_n: unit = bm * tiles_n + bn.
-__device__ __forceinline__ void wf_unit(int lid, const WfMagic &mg, int &bm, int &bn)
+__host__ __device__ __forceinline__ void wf_unit(int lid, const WfMagic &mg, int &bm, int &bn)
 {
     const int grp = wf_div(lid, mg.upg_m);
     const int r = lid - grp * mg.upg;

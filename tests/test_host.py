@@ -305,3 +305,46 @@ def test_create_error_text_comes_back_through_the_out_parameter():
     assert rc < 0 and not h.value and len(buf.value) > 0          # "no HIP device available" here, the parser's text on a GPU box
     small = C.create_string_buffer(8)
     assert L.apr_engine_create_ex(b"not a model", 11, 0, 8, C.byref(h), small, len(small)) < 0 and len(small.value) == 7
+
+
+def test_unit_order_of_the_persistent_kernels_is_a_bijection(tmp_path):
+    # wf_magic / wf_unit (csrc/wino_fused.hip.h): unit index -> (M tile, N tile) with the N tiles in groups of gn.  Every (bm, bn)
+    # exactly once, also for N-tile counts that 4 does not divide (the group size falls back to a divisor) and for the
+    # unit counts of BASELINE config 2; a run of consecutive units stays within one group of N tiles.
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "unit_order.cpp"
+    src.write_text(r"""
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "wino_fused.hip.h"
+int main()
+{
+    const long long cases[][3] = {{7, 3, 4}, {5, 6, 4}, {1, 16, 4}, {13, 12, 0}, {9, 8, 1}, {48128, 2, 4}, {3072, 8, 4}, {192, 16, 4}, {1536, 8, 4}, {11, 5, 4}};
+    for (auto &c : cases) {
+        const long long tm = c[0]; const int tn = (int)c[1], gn_req = (int)c[2];
+        const apr::WfMagic mg = apr::wf_magic(tn, 3, 5, tm, gn_req);
+        if (tn % mg.gn || mg.gn < 1 || (gn_req >= 1 && mg.gn > gn_req) || mg.upg != tm * mg.gn) { printf("bad group %d for %d\n", mg.gn, tn); return 1; }
+        std::vector<int> seen((size_t)tm * tn, 0);
+        for (long long lid = 0; lid < tm * tn; lid++) {
+            int bm, bn;
+            apr::wf_unit((int)lid, mg, bm, bn);
+            if (bm < 0 || bm >= tm || bn < 0 || bn >= tn) { printf("out of range\n"); return 1; }
+            if (bn / mg.gn != lid / mg.upg) { printf("unit %lld left its group\n", lid); return 1; }
+            seen[(size_t)bm * tn + bn]++;
+        }
+        for (int v : seen) if (v != 1) { printf("not a bijection\n"); return 1; }
+    }
+    printf("ok\n");
+    return 0;
+}
+""")
+    exe = tmp_path / "unit_order"
+    subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(REPO, "apr_amd", "csrc"), "-I", os.path.join(REPO, "include"),
+                    str(src), "-o", str(exe)], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, timeout=60)
+    assert out.stdout.strip() == b"ok"
