@@ -281,6 +281,11 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
         assert not np.array_equal(direct, got)          # really different arithmetic
     assert not np.array_equal(unfused, fused)
     assert np.array_equal(fused, fused1)                # batch size / chunking is bit-invisible
+    # the unit order of the persistent kernels (wf_unit: N tiles in groups) is bit-invisible too: groups of 1, 2 and "all"
+    s2f = {"APR_WINO_S2_FUSED_MIN_BATCH": "1", "APR_WINO_S2_FUSED_MIN_CIN": "128", "APR_WINO_S2_FUSED_MIN_PX": "1"}
+    ref = run({"APR_WINO_FUSED_MAX_CIN": "512", **s2f})
+    for gn in ("1", "2", "64"):
+        assert np.array_equal(ref, run({"APR_WINO_FUSED_MAX_CIN": "512", "APR_WINO_GN": gn, "APR_WINO_S2_GN": gn, **s2f}))
 
 
 def test_stride2_polyphase_winograd_layers(he_weights, monkeypatch):
