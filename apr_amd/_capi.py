@@ -19,7 +19,7 @@ STATIC_MAX_WINDOWS = 64
 SYMBOLS = (
     "apr_device_count", "apr_version", "apr_engine_create", "apr_engine_destroy", "apr_engine_num_classes",
     "apr_last_error", "apr_prepare", "apr_prepare_batch", "apr_infer", "apr_score", "apr_score_device",
-    "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable",
+    "apr_prepare_batch_device", "apr_infer_device", "apr_sync", "apr_engine_stream", "apr_profile_enable", "apr_mfma_probe",
     "apr_profile_reset", "apr_profile_read", "apr_synth_pcm", "apr_model_info", "apr_classify", "apr_classify_device",
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
     "apr_resample_taps", "apr_upsample", "apr_upsample_device", "apr_stream_tick", "apr_stream_buffer", "apr_stream_reset",
@@ -128,6 +128,8 @@ def lib():
     L.apr_sync.restype = C.c_int
     L.apr_engine_stream.argtypes = [vp]
     L.apr_engine_stream.restype = C.c_void_p
+    L.apr_mfma_probe.argtypes = [vp, C.POINTER(C.c_double)]
+    L.apr_mfma_probe.restype = C.c_int
     L.apr_profile_enable.argtypes = [vp, C.c_int]
     L.apr_profile_enable.restype = C.c_int
     L.apr_profile_reset.argtypes = [vp]

@@ -121,6 +121,7 @@ struct apr_engine {
     float *d_wfc = nullptr, *d_bfc = nullptr;
     float *d_V = nullptr, *d_M = nullptr;   // Winograd-domain activations [16][T][Cin] / [16][T][Cout]
     float *d_part = nullptr;                // split-K partial sums [ksplit][M][Cout]
+    float *d_probe = nullptr;               // apr_mfma_probe's sink
 
     // staging for the host-pointer entry points
     uint8_t *d_pcm = nullptr;
@@ -1685,6 +1686,39 @@ int apr_profile_enable(apr_engine *e, int on)
     if (!on) rc = prof_flush(e);
     e->prof_on = on != 0;
     return rc;
+}
+
+int apr_mfma_probe(apr_engine *e, double *tflops)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (!tflops) { e->err = "apr_mfma_probe: bad argument"; return APR_ERR_INVALID; }
+    if (!e->d_probe && (rc = dev_alloc(e, &e->d_probe, (size_t)64))) return rc;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        if (a) (void)hipEventDestroy(a);
+        e->err = "apr_mfma_probe: no events";
+        return APR_ERR_DEVICE;
+    }
+    const int iters = 4096, blocks = e->n_cus * 2;            // 8 waves per CU: two per SIMD
+    double best = 0.0;
+    for (int r = 0; r < 3; r++) {                              // the first round also warms the clock up
+        (void)hipEventRecord(a, e->stream);
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, e->stream, e->d_probe, iters);
+        (void)hipEventRecord(b, e->stream);
+        float ms = 0.0f;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess || ms <= 0.0f) {
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+            e->err = "apr_mfma_probe: launch failed";
+            return APR_ERR_DEVICE;
+        }
+        const double flop = (double)blocks * 4.0 * iters * 8.0 * 4096.0;   // waves x iterations x 8 MFMAs x 2*32*32*2
+        best = std::max(best, flop / (ms * 1e-3) / 1e12);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *tflops = best;
+    return APR_OK;
 }
 
 int apr_profile_reset(apr_engine *e)

@@ -31,4 +31,29 @@ __global__ __launch_bounds__(256) void bucket_hits_kernel(const int32_t *__restr
     }
 }
 
+// apr_mfma_probe: v_mfma_f32_32x32x2_f32 back to back from registers, eight independent accumulators a wave (data that is
+// neither zero nor constant across lanes: the clock a chip holds depends on it).
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float *sink, int iters)
+{
+    typedef float pf16 __attribute__((ext_vector_type(16)));
+    const int lane = threadIdx.x & 63;
+    float a = 0.001f * (float)(lane + 1), b = 1.0f - 0.002f * (float)lane;
+    pf16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        a = -a;                                                // keeps the sums bounded
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += acc[i][j];
+    if (s == 12345.678f) sink[0] = s;                          // never true: keeps the loop alive
+}
+
 }  // namespace apr

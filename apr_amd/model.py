@@ -290,6 +290,12 @@ class Engine:
         self._chk(self._lib.apr_sync(self._h))
 
     # ---- profiling ----
+    def mfma_probe(self) -> float:
+        """fp32 matrix TFLOP/s this GPU delivers right now (apr_mfma_probe; a diagnostic)"""
+        v = C.c_double(0.0)
+        self._chk(self._lib.apr_mfma_probe(self._h, C.byref(v)))
+        return float(v.value)
+
     def profile_enable(self, on: bool = True) -> None:
         self._chk(self._lib.apr_profile_enable(self._h, 1 if on else 0))
 

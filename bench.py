@@ -354,6 +354,11 @@ def main() -> int:
                            "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
                            "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"],
                            "share_of_gpu_time": dom["ms"] / tot_ms}
+        # the fp32 matrix rate the box delivers right after the timed steps (MFMAs from registers, no memory): a throttled box
+        # lowers this and roofline.achieved alike, a slower build lowers only the latter
+        probe = eng.mfma_probe()
+        out["mfma_probe"] = {"tflops": probe, "frac_of_peak": probe / PEAK_F32_MFMA_TFLOPS,
+                             "dominant_kernel_vs_probe": ach / probe if probe else None}
 
         def stage(k, v):
             tf = (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None

@@ -314,6 +314,11 @@ typedef struct apr_profile_slot {
     double   bytes;        /* algorithmic HBM bytes of those launches           */
 } apr_profile_slot;
 int apr_profile_enable(apr_engine *e, int on);
+/* Diagnostic with no counterpart in the reference: the fp32 matrix rate this GPU delivers right now.  Every SIMD issues
+ * v_mfma_f32_32x32x2_f32 back to back from registers (no memory traffic) for a few milliseconds on the engine's stream;
+ * *tflops = the rate by HIP events.  bench.py prints it beside the roofline so that a throttled box (one of round 2's ran
+ * every kernel 15 % slower) can be told from a slower build. */
+int apr_mfma_probe(apr_engine *e, double *tflops);
 int apr_profile_reset(apr_engine *e);
 int apr_profile_read(apr_engine *e, apr_profile_slot *slots /*[APR_PROF_SLOTS]*/, int *n_slots);
 

@@ -503,3 +503,12 @@ def test_upsample_bit_exact_with_oracle_definition(fe):
     assert np.abs(up[300:-300] - ref[300:-300]).max() <= 8.0           # 1 kHz: passband ripple + input/output rounding
     with pytest.raises(AprError):
         fe.upsample(x[:10], 3, np.zeros((3, 31)))
+
+
+def test_mfma_probe_is_a_sane_rate(fe):
+    # apr_mfma_probe (a diagnostic, no reference counterpart): between a badly throttled chip and the fp32 matrix peak of
+    # 157.3 TFLOP/s at 2.4 GHz (MI355X_MICROARCH.md); two calls on a warm chip agree within 10 %
+    a = fe.mfma_probe()
+    b = fe.mfma_probe()
+    assert 60.0 < a < 160.0 and 60.0 < b < 160.0
+    assert abs(a - b) / max(a, b) < 0.10
