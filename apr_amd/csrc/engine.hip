@@ -649,7 +649,7 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             ProfScope ps(e, L.slot, 2.0 * 16.0 * (double)T * L.cin * L.cout, bytes + 4.0 * 7.0 * L.cin * L.cout);
             if (L.fused_waves == 4)
                 hipLaunchKernelGGL(wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), WF_LDS_BYTES, e->stream, in, L.d_u, L.d_b,
-                                   out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw));
+                                   out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw, tiles_m));
             else
                 hipLaunchKernelGGL(wino_fused8_f2, dim3(wf8_grid((int)(tiles_m * tiles_n), e->n_cus)), dim3(512), WF8_LDS_BYTES, e->stream, in, L.d_u,
                                    L.d_b, out, L.hin, L.win, L.cin, L.cout, L.th, L.tw, (int)T, tiles_n, wf_magic(tiles_n, L.th, L.tw, tiles_m, L.gn), (int)(tiles_m * tiles_n));

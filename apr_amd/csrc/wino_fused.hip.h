@@ -126,7 +126,8 @@ __host__ __device__ __forceinline__ void wf_unit(int lid, const WfMagic &mg, int
     bm = wf_div(r, mg.gn_m);
     bn = grp * mg.gn + (r - bm * mg.gn);
 }
-inline WfMagic wf_magic(int tiles_n, int th, int tw, long long tiles_m = 1, int gn = 0)
+// tiles_m has no default on purpose: a unit order built for another M extent sends units to N tiles that do not exist
+inline WfMagic wf_magic(int tiles_n, int th, int tw, long long tiles_m, int gn = 0)
 {
     auto mk = [](long long d) { return (unsigned long long)(((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d); };
     if (gn < 1 || gn > tiles_n) gn = tiles_n;

@@ -25,6 +25,17 @@ namespace apr {
 #define W8_ABL 0   // developer timing ablations (tools/wino_fused_bench.cpp): 1 no patch loads, 2 no transform/stores, 4 no U DMA, 8 no barrier
 #endif
 
+#ifdef W8_USTAMPS  // developer build (tools/wino_fused_bench.cpp): s_memtime per wave of workgroup 0, summed over its units: [0] next unit's set-up +
+                   // first loads, [1] first half of the epilogue, [2] its barrier, [3] second half + stores issued, [4] end-of-unit barrier,
+                   // [5] prologue transform + stores, [6] prologue barrier, [7] K loop
+__device__ unsigned long long w8_ustamps[8][10];   // [8] the set-up part of [0]
+#define W8_US(I_) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); us8[I_] += t_ - ust; ust = t_; }
+#define W8_UK(I_) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); uk8[I_] += t_ - ukt; ukt = t_; }
+__device__ unsigned long long w8_ksteps[8][8];     // cycles per K step: the two first, the loop's two (summed), the last four
+#else
+#define W8_US(I_)
+#define W8_UK(I_)
+#endif
 #ifdef W8_STAMPS   // developer build (tools/ws_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles waited at the barrier of
                    // its load steps [0] / store steps [1], K loop total [6], steps [7]
 __device__ unsigned long long w8_stamps[8][8];
@@ -113,18 +124,18 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     }
     // descriptors of a unit: its window's image (one row and one column early, so every valid tap has a
     // non-negative offset) and its N tile's U image
-#define W8_DESCRIPTORS(BN_, B0_)                                                                         \
+#define W8_DESCRIPTORS(RSU_, BN_, B0_)                                                                   \
     {                                                                                                    \
         rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (((long long)(B0_) * H - 1) * W - 1) * (long long)Cin), 0, 0x40000000, 0x00020000); \
         const unsigned long long ub_ = (unsigned long long)(up + (size_t)(BN_) * KC * WF_POS);           \
-        rsU.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub_);                                      \
-        rsU.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub_ >> 32) & 0xFFFF);                     \
+        RSU_.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub_);                                     \
+        RSU_.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub_ >> 32) & 0xFFFF);                    \
     }
     const int KC = Cin / WF_BK;
     __amdgpu_buffer_rsrc_t rsA;
-    i32x4 rsU;
-    rsU.z = 0x7FFFFFFF;
-    rsU.w = 0x00020000;
+    i32x4 rsU, rsU_n;                           // this unit's U image; the next unit's (set up inside the K loop)
+    rsU.z = rsU_n.z = 0x7FFFFFFF;
+    rsU.w = rsU_n.w = 0x00020000;
     const unsigned us_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(Us + (wave & 3) * (WF_POS / 4)));
     const unsigned uvoff = (unsigned)((wave & 3) * (WF_POS / 4) * 4 + lane * 16);
 
@@ -137,12 +148,12 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 #define W8_FIRST_LOADS()                                                                                 \
     {                                                                                                    \
         if (dma_wave) {                                                                                  \
-            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) W8_DMA_U1(0, 0, i_)                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) W8_DMA_U1(rsU, 0, 0, i_)                    \
         }                                                                                                \
         _Pragma("unroll") for (int ij_ = 0; ij_ < 16; ij_++) W8_LOAD_V1(phs, ij_)  /* KC >= 2 */          \
     }
 #define W8_LOAD_V1(KC_, IJ_) d[IJ_] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsA, vo[IJ_], 4 * (KC_) * WF_BK, 0));
-#define W8_DMA_U1(KC_, BUF_, I_) lds_dma_b128(rsU, uvoff, __builtin_amdgcn_readfirstlane((KC_) * (WF_POS * 4) + (I_) * 1024), __builtin_amdgcn_readfirstlane(us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024)));
+#define W8_DMA_U1(RSU_, KC_, BUF_, I_) lds_dma_b128(RSU_, uvoff, __builtin_amdgcn_readfirstlane((KC_) * (WF_POS * 4) + (I_) * 1024), __builtin_amdgcn_readfirstlane(us_lds + (unsigned)((BUF_) * WF_POS * 4 + (I_) * 1024)));
 #define W8_ROWS()                                                                                        \
     {                                                                                                    \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)                                                 \
@@ -211,10 +222,13 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 #define W8_LOADWAIT_STAMPED(ROLE, SL)
 #define W8_BAR_STAMPED(ROLE) if (!(W8_ABL & 8)) __syncthreads();
 #endif
-#define W8_KSTEP(ROLE, FIRST)                                                                            \
+#define W8_KSTEP(ROLE, FIRST, OFFS, SID)                                                                          \
     {                                                                                                    \
-        const int kn1 = kc + 1 < KC ? kc + 1 : KC - 1;                                                   \
-        const int kn2 = kc + 2 < KC ? kc + 2 : KC - 1;                                                   \
+        /* chunks past the end are the next unit's chunks 0 and 1 (the last unit of a workgroup: its own again, staging nobody reads) */ \
+        const int kn1 = kc + 1 < KC ? kc + 1 : 0;                                                        \
+        const int kn2 = kc + 2 < KC ? kc + 2 : kc + 2 - KC;                                              \
+        i32x4 rsUs = rsU;                                                                                \
+        if (kc + 1 >= KC) { rsUs.x = rsU_n.x; rsUs.y = rsU_n.y; }                                        \
         _Pragma("unroll") for (int g = 0; g < 4; g++)                                                    \
         {                                                                                                \
             _Pragma("unroll") for (int i = 0; i < 8; i++)                                                \
@@ -229,30 +243,54 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
                     if (g < 3) W8_READ_OP((g + 1) & 1, cur, g + 1, i)                                    \
                     else W8_READ_OP(0, cur ^ 1, 0, i)                                                    \
                 }                                                                                        \
-                if (!(W8_ABL & 4) && dma_wave && ROLE == 0 && sl < 16 && (sl & 1) == 0) W8_DMA_U1(kn1, cur ^ 1, sl >> 1) \
+                if (!(W8_ABL & 4) && dma_wave && ROLE == 0 && sl < 16 && (sl & 1) == 0) W8_DMA_U1(rsUs, kn1, cur ^ 1, sl >> 1) \
                 if (!(W8_ABL & 1) && ROLE == 0 && sl < 16) W8_LOAD_V1(kn2, sl)                           \
                 W8_LOADWAIT_STAMPED(ROLE, sl)                                                            \
                 if (!(W8_ABL & 2) && ROLE == 1 && sl == 0) W8_ROWS()                                     \
-                if (!(W8_ABL & 4) && dma_wave && ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(kn1, cur ^ 1, sl - 1) \
+                if (!(W8_ABL & 4) && dma_wave && ROLE == 1 && sl >= 1 && sl <= 8) W8_DMA_U1(rsUs, kn1, cur ^ 1, sl - 1) \
                 if (!(W8_ABL & 2) && ROLE == 1 && sl >= 10 && sl <= 22 && ((sl - 10) & 3) == 0) {        \
                     _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) W8_STORE_POS(cur ^ 1, (sl - 10) >> 2, q_) \
+                }                                                                                        \
+                if (ROLE == 1 && (OFFS) && sl == 25) {                                                   \
+                    /* this wave's next load step takes the next unit's chunk 0 / 1: its offsets and descriptors, now */ \
+                    W8_DESCRIPTORS(rsU_n, bn_n, b0_n)                                                    \
+                    W8_OFFSETS(voff_n, vmask_n)                                                          \
                 }                                                                                        \
                 acc[2 * g + (i & 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i & 1][i >> 1], bf[g & 1][i & 1][i >> 1], (FIRST) && i < 2 ? zero16 : acc[2 * g + (i & 1)], 0, 0, 0); \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
             }                                                                                            \
         }                                                                                                \
         cur ^= 1;                                                                                        \
+        W8_UK(SID)                                                                                       \
     }
 
 
+#ifdef W8_USTAMPS
+    unsigned us8[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned ust;
+    unsigned uk8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned ukt;
+#endif
     int bn, b0, tb = 0;
+    int bn_n = 0, b0_n = 0;
     {
         unsigned voff, vmask;
         W8_SETUP(x_start + lidl, 0, bn, b0, voff, vmask)
-        W8_DESCRIPTORS(bn, b0)
+        W8_DESCRIPTORS(rsU, bn, b0)
         W8_OFFSETS(voff, vmask)
     }
+    // ---- the workgroup's first unit: first loads, parity 0 stages chunk 0.  Every later unit is staged by the K loop of
+    //      the unit before it: the loads, transform, stores and U DMA of its last two steps, which have no chunk of their
+    //      own left to fetch, take the next unit's chunks 0 and 1, so the staging pipeline never drains ----
     W8_FIRST_LOADS()
+    if (ph == 0) {
+        W8_ROWS()
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
+    }
+    if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the U DMA has landed
     for (;;) {
         WF_STAMP(1)
         // this unit's bias, now: a load issued in the epilogue would be younger than the next unit's patch loads and
@@ -260,17 +298,19 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         const int n = bn * WF_BN + wn * 32 + li;
         const float bv = bias[n];
         __builtin_amdgcn_sched_barrier(0);
-        // ---- prologue of a unit: its first loads are already in flight (issued above, or before the previous
-        //      unit's epilogue); parity 0 stages chunk 0 ----
-        if (ph == 0) {
-            W8_ROWS()
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int qq = 0; qq < 4; qq++) W8_STORE_POS(0, i, qq)
-        }
-        if (dma_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the U DMA has landed (parity 1: and chunk 1, which its step 0 transforms at once)
-        __syncthreads();
+#ifdef W8_USTAMPS
+        ust = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+        const int nl = lidl + per;
+        const bool more = nl < x_count;             // workgroup-uniform
+        __syncthreads();                            // chunk 0 is in Vs[0] / Us[0]; every wave is done with the last unit's exchange and tile table
+        W8_US(6)
+        // the next unit's tile arithmetic, here, where the accumulators are not live yet (its tile table replaces the last
+        // unit's); the K loop expands it to offsets when this unit's last chunk has been loaded.  The last unit of a
+        // workgroup prepares itself again: loads of valid memory into staging that nobody reads
+        unsigned voff_n, vmask_n;
+        W8_SETUP(x_start + (more ? nl : lidl), tb ^ 1, bn_n, b0_n, voff_n, vmask_n)
+        W8_US(5)
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) W8_READ_OP(0, 0, 0, qq)
 
@@ -279,63 +319,71 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 #ifdef W8_STAMPS
         const unsigned tk0 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
+#ifdef W8_USTAMPS
+        ukt = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
         // the first step's first MFMA of every accumulator takes C = 0: no clearing pass (128 v_mov a wave)
+        // KC is even and >= 6.  The step that ends a wave's loads of this unit (KC - 3 for parity 0, KC - 2 for parity 1, its
+        // store role) turns the next unit's tile arithmetic into the wave's offsets: the last four steps are straight-line
+        // code of their own (a branch around that piece inside the loop costs hipcc 700 spilled registers)
         if (phs == 0) {
-            {
-                int kc = 0;
-                W8_KSTEP(0, true)
-                kc = 1;
-                W8_KSTEP(1, false)
-            }
-            for (int kc = 2; kc < KC; kc += 2) {   // KC is even
-                W8_KSTEP(0, false)
+            int kc = 0;
+            W8_KSTEP(0, true, 0, 0)
+            kc = 1;
+            W8_KSTEP(1, false, 0, 1)
+            for (kc = 2; kc < KC - 4; kc += 2) {
+                W8_KSTEP(0, false, 0, 2)
                 kc++;
-                W8_KSTEP(1, false)
+                W8_KSTEP(1, false, 0, 3)
                 kc--;
             }
+            W8_KSTEP(0, false, 0, 4)
+            kc++;
+            W8_KSTEP(1, false, 1, 5)
+            kc++;
+            W8_KSTEP(0, false, 0, 6)
+            kc++;
+            W8_KSTEP(1, false, 0, 7)
         } else {
-            {
-                int kc = 0;
-                W8_KSTEP(1, true)
-                kc = 1;
-                W8_KSTEP(0, false)
-            }
-            for (int kc = 2; kc < KC; kc += 2) {
-                W8_KSTEP(1, false)
+            int kc = 0;
+            W8_KSTEP(1, true, 0, 0)
+            kc = 1;
+            W8_KSTEP(0, false, 0, 1)
+            for (kc = 2; kc < KC - 4; kc += 2) {
+                W8_KSTEP(1, false, 0, 2)
                 kc++;
-                W8_KSTEP(0, false)
+                W8_KSTEP(0, false, 0, 3)
                 kc--;
             }
+            W8_KSTEP(1, false, 0, 4)
+            kc++;
+            W8_KSTEP(0, false, 0, 5)
+            kc++;
+            W8_KSTEP(1, false, 1, 6)
+            kc++;
+            W8_KSTEP(0, false, 0, 7)
         }
 #ifdef W8_STAMPS
         st8[6] += (unsigned)__builtin_amdgcn_s_memtime() - tk0;
         st8[7] += KC;
 #endif
+        W8_US(7)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         f32x2 bv2 = {bv, bv};
         asm volatile("" : "+v"(bv2));   // hipcc's own wait for the bias load goes here, where nothing is in flight
         WF_STAMP(3)
 
-        // ---- the next unit's set-up and first loads go out before this unit's epilogue: d[] and vo[] are free,
-        //      Us[0] was last read a K step ago, the tile table has a second copy ----
-        const int nl = lidl + per;
-        const bool more = nl < x_count;             // workgroup-uniform
-        int bn_n = 0, b0_n = 0;
-        if (more) {
-            unsigned voff, vmask;
-            W8_SETUP(x_start + nl, tb ^ 1, bn_n, b0_n, voff, vmask)
-            W8_DESCRIPTORS(bn_n, b0_n)
-            W8_OFFSETS(voff, vmask)
-            W8_FIRST_LOADS()
-        }
+        // (the next unit's chunk 0 is in Vs[0] / Us[0] by now, its chunk 1 in parity 1's registers)
         WF_STAMP(4)
+        W8_US(0)
 
         // ---- epilogue.  acc[q][e]: position ph*8 + q = row 2 ph + q/4, column q%4 of the 4x4 m; e -> tile row
         //      (e&3) + 8*(e>>2) + 4*(lane>>5), lane&31 -> channel.  A^T = [1 1 1 0; 0 1 -1 -1].
         //      partial outputs of this wave's two m rows; the pair swaps halves through LDS:
         //      parity 0 finishes pixels (0,0),(0,1), parity 1 finishes (1,0),(1,1) ----
-        float *xw = Vs + ((sub * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [2 ep + column][lane][2]
-        const float *xr = Vs + ((sub * 2 + (ph ^ 1)) * 16) * 128 + lane * 2;   // what it receives
+        //      The exchange runs through the buffers the last K step read, Vs[1] (pairs 0, 1) and Us[1] (pairs 2, 3).
+        float *xw = wf_smem + (2 * (sub >> 1) + 1) * WF_POS + (((sub & 1) * 2 + ph) * 16) * 128 + lane * 2;          // what this wave hands over   [2 ep + column][lane][2]
+        const float *xr = wf_smem + (2 * (sub >> 1) + 1) * WF_POS + (((sub & 1) * 2 + (ph ^ 1)) * 16) * 128 + lane * 2;   // what it receives
         // two tile rows (e = 2 ep, 2 ep + 1: neighbouring accumulator registers) per packed instruction
         f32x2 keep[8][2];
         // PH_ is a literal: two straight-line copies, chosen once by the (scalar) parity
@@ -360,7 +408,9 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
         }
         if (phs == 0) { W8_EPI_FIRST(0) } else { W8_EPI_FIRST(1) }
 #undef W8_EPI_FIRST
+        W8_US(1)
         __syncthreads();
+        W8_US(2)
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
         const unsigned nb4 = 4u * (unsigned)n;
         // parity 0 finishes the tile's pixels (0,0), (0,1), parity 1 (1,0), (1,1): its half of the tile's table row
@@ -381,13 +431,20 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
             }
         }
         WF_STAMP(5)
+        W8_US(3)
         if (!more) break;
-        __syncthreads();    // every wave has read its half of the exchange: Vs may be staged again
         bn = bn_n; b0 = b0_n; tb ^= 1; lidl = nl;
+        rsU.x = rsU_n.x; rsU.y = rsU_n.y;
     }
 #ifdef W8_STAMPS
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; i++) w8_stamps[wave][i] += st8[i];
+#endif
+#ifdef W8_USTAMPS
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 10; i++) w8_ustamps[wave][i] += us8[i];
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; i++) w8_ksteps[wave][i] += uk8[i];
 #endif
 #undef W8_KSTEP
 #undef W8_BAR_STAMPED

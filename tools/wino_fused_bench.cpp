@@ -74,9 +74,9 @@ int main(int argc, char **argv)
     (void)hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, 0);
     auto launch = [&]() {
         if (k8)
-            hipLaunchKernelGGL(apr::wino_fused8_f2, dim3(apr::wf8_grid((int)(tiles_m * tiles_n), n_cus)), dim3(512), apr::WF8_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw), (int)(tiles_m * tiles_n));
+            hipLaunchKernelGGL(apr::wino_fused8_f2, dim3(apr::wf8_grid((int)(tiles_m * tiles_n), n_cus)), dim3(512), apr::WF8_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw, tiles_m, getenv("WF_GN") ? atoi(getenv("WF_GN")) : 4), (int)(tiles_m * tiles_n));
         else
-        hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw));
+        hipLaunchKernelGGL(apr::wino_fused_f2, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), apr::WF_LDS_BYTES, 0, d_in, d_u, d_b, d_out, H, W, Cin, Cout, th, tw, (int)T, tiles_n, apr::wf_magic(tiles_n, th, tw, tiles_m));
     };
     launch();
     CK(hipGetLastError());
@@ -120,6 +120,28 @@ int main(int argc, char **argv)
         }
         printf("gap between a block's end and the next block's first instruction on the same CU: %.0f ticks (%d pairs)\n", ng ? gap / ng : 0.0, ng);
         printf("block 0: %llu %llu %llu %llu %llu %llu hwid %llx\n", h[0][0], h[0][1] - h[0][0], h[0][2] - h[0][0], h[0][3] - h[0][0], h[0][4] - h[0][0], h[0][5] - h[0][0], h[0][6]);
+    }
+#endif
+#ifdef W8_USTAMPS
+    {
+        unsigned long long h[8][10];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(apr::w8_ustamps), sizeof h));
+        const double units = (double)(reps + 1) * ((tiles_m * tiles_n + apr::wf8_grid((int)(tiles_m * tiles_n), n_cus) - 1) / apr::wf8_grid((int)(tiles_m * tiles_n), n_cus));
+        printf("cycles per unit of workgroup 0 (about %.0f units): next set-up+loads | epi 1 | barrier | epi 2+stores | barrier | prologue | barrier | K loop\n", units);
+        for (int w = 0; w < 8; w++) {
+            printf("  wave %d:", w);
+            printf(" (set-up %5.0f)", (double)h[w][8] / units);
+            for (int i = 0; i < 8; i++) printf(" %7.0f", (double)h[w][i] / units);
+            printf("\n");
+        }
+        unsigned long long k[8][8];
+        CK(hipMemcpyFromSymbol(k, HIP_SYMBOL(apr::w8_ksteps), sizeof k));
+        printf("cycles per K step: first two | the loop's two (sum over its passes) | last four\n");
+        for (int w = 0; w < 8; w++) {
+            printf("  wave %d:", w);
+            for (int i = 0; i < 8; i++) printf(" %7.0f", (double)k[w][i] / units);
+            printf("\n");
+        }
     }
 #endif
     if (argc > 7) return 0;   // timing-only ablation builds
