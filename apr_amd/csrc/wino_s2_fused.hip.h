@@ -102,21 +102,32 @@ struct WsCtx {   // per-wave constants of the whole launch
 struct WsUnit {   // what changes from unit to unit
     __amdgpu_buffer_rsrc_t rsA;
     i32x4 rsU;
-    int bn, b0;
+    int bn, b0, g0;                              // N tile, first window, first tile
 };
 
-// unit lid -> its N tile, first window, descriptors, this lane's 25 patch offsets (padding = out-of-range offsets), and
-// (write_tbl) the tile table: byte offsets of every tile's four output pixels, out of range if absent
-__device__ __forceinline__ void ws_setup(const WsArgs &a, const WsCtx &c, int lid, int tb, bool write_tbl, WsUnit &u, unsigned (&vo)[25])
+// unit lid -> its N tile, first tile and window, descriptors (wave-uniform)
+__device__ __forceinline__ void ws_setup_unit(const WsArgs &a, const WsCtx &c, int lid, WsUnit &u)
 {
-    constexpr unsigned OOB = 0x80000000u;
     int bm;
     wf_unit(lid, a.mg, bm, u.bn);
-    const int g0 = bm * WS_TT;                   // first tile of the unit (< T)
-    u.b0 = wf_div(g0, a.mg.tpw);                 // its window
+    u.g0 = bm * WS_TT;                           // first tile of the unit (< T)
+    u.b0 = wf_div(u.g0, a.mg.tpw);               // its window
+    u.rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (((long long)u.b0 * a.H - 1) * a.W - 1) * (long long)a.Cin), 0, 0x40000000, 0x00020000);
+    const unsigned long long ub = (unsigned long long)(a.up + (size_t)u.bn * c.KC * WS_UIMG);
+    u.rsU.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub);
+    u.rsU.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32) & 0xFFFF);
+    u.rsU.z = 0x7FFFFFFF;
+    u.rsU.w = 0x00020000;
+}
+
+// this lane's 25 patch offsets in unit u (padding = out-of-range offsets), and (write_tbl) the tile table: byte offsets of
+// every tile's four output pixels, out of range if absent
+__device__ __forceinline__ void ws_setup_lanes(const WsArgs &a, const WsCtx &c, const WsUnit &u, int tb, bool write_tbl, unsigned (&vo)[25])
+{
+    constexpr unsigned OOB = 0x80000000u;
     unsigned voff = OOB, vmask = 0;
     u32x4 to = {OOB, OOB, OOB, OOB};
-    const int g = g0 + c.t_ld;
+    const int g = u.g0 + c.t_ld;
     if (g < a.T) {
         const int rr = wf_div(g, a.mg.tw);
         const int tx = g - rr * a.tw;
@@ -144,12 +155,6 @@ __device__ __forceinline__ void ws_setup(const WsArgs &a, const WsCtx &c, int li
 #pragma unroll
     for (int ij = 0; ij < 25; ij++)
         vo[ij] = ((vmask >> ij) & 1u) ? voff + 4u * (unsigned)(((ij / 5) * a.W + (ij % 5)) * a.Cin) : OOB;
-    u.rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (((long long)u.b0 * a.H - 1) * a.W - 1) * (long long)a.Cin), 0, 0x40000000, 0x00020000);
-    const unsigned long long ub = (unsigned long long)(a.up + (size_t)u.bn * c.KC * WS_UIMG);
-    u.rsU.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ub);
-    u.rsU.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32) & 0xFFFF);
-    u.rsU.z = 0x7FFFFFFF;
-    u.rsU.w = 0x00020000;
 }
 
 // rows: d <- B^T d per patch column, B^T d = [d0 - d2, d2, d4 - d2, d1, d3]
@@ -207,16 +212,22 @@ __device__ __forceinline__ void ws_first_loads(const WsCtx &c, const WsUnit &u, 
 
 // K step kc (phase PH = kc mod 4) of a wave of group Q: one MFMA per slot, each closed by a full scheduling barrier so that
 // the staging work stays where it is written, a slot's worth at a time, in the shadow of the MFMAs.
-template <int PS, int WN, int PH>
-__device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc, int &cur, f32x16 (&acc)[3], f32x4 (&af)[2], f32x4 (&bf)[2],
-                                         f32x2 (&d)[25], const unsigned (&vo)[25] WS_ST_ARG)
+// TAIL: one of the unit's last four steps (kc = KC - 4 + PH).  Their staging has no chunk of this unit left to fetch beyond
+// KC - 1: it takes chunks 0, 1, 2 and U(0) of the workgroup's next unit un, so the pipeline runs on across the unit boundary;
+// a group turns to the next unit in its idle step of the four (ROLE 0, after the barrier: its registers d are free then).
+template <int PS, int WN, int PH, bool TAIL>
+__device__ __forceinline__ void ws_kstep(const WsArgs &a, const WsCtx &c, const WsUnit &u, const WsUnit &un, int tb, int kc, int &cur, f32x16 (&acc)[3],
+                                         f32x4 (&af)[2], f32x4 (&bf)[2], f32x2 (&d)[25], unsigned (&vo)[25] WS_ST_ARG)
 {
     constexpr int Q = ws_q(PS);
     constexpr int NP = ws_np(PS);
     constexpr int ROLE = (Q - PH + 4) & 3;   // 3: load chunk kc+3, 2: transform chunk kc+2, 1: store chunk kc+1 (+ U DMA), 0: U DMA only
     constexpr int SET0 = (PH * NP) & 1;      // operand register set of this step's first position
-    const int kn1 = kc + 1 < c.KC ? kc + 1 : c.KC - 1;   // chunk indices past the end are clamped (staging nobody reads)
-    const int kn3 = kc + 3 < c.KC ? kc + 3 : c.KC - 1;
+    constexpr bool NEXT_V = TAIL && PH >= 1, NEXT_U = TAIL && PH == 3;
+    const int kn1 = NEXT_U ? 0 : kc + 1;
+    const int kn3 = NEXT_V ? PH - 1 : kc + 3;
+    const WsUnit &uv = NEXT_V ? un : u;
+    const WsUnit &uu = NEXT_U ? un : u;
 #pragma unroll
     for (int n = 0; n < NP; n++) {
 #pragma unroll
@@ -243,8 +254,8 @@ __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc
                 else bf[set ^ 1] = *reinterpret_cast<const f32x4 *>(c.Us + buf * WS_UIMG + um * (WS_BN * WS_BK) + c.rd_u);
             }
             if (ROLE == 3 && !(WS_ABL & 4)) {   // patch loads of chunk kc+3: one per slot (24 slots at least), the 25th with the 24th
-                if (sl < 24) d[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u.rsA, vo[sl], 4 * kn3 * WS_BK, 0));
-                if (sl == 23) d[24] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(u.rsA, vo[24], 4 * kn3 * WS_BK, 0));
+                if (sl < 24) d[sl] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(uv.rsA, vo[sl], 4 * kn3 * WS_BK, 0));
+                if (sl == 23) d[24] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(uv.rsA, vo[24], 4 * kn3 * WS_BK, 0));
             }
             // B^T d B of chunk kc+2 in the step before its store step (its loads went out a step ago)
             if (ROLE == 2 && !(WS_ABL & 8)) {
@@ -255,7 +266,8 @@ __device__ __forceinline__ void ws_kstep(const WsCtx &c, const WsUnit &u, int kc
             // U(kc+1), 1 KiB a slot, by the waves of channel half 0 only (of the two waves of a SIMD the one with the lower id is
             // served first, tools/ws_stamps.py: its staging work runs beside the other wave's MFMAs, the other wave's does not)
             if (!(WS_ABL & 2) && WN == 0 && ((ROLE == 0 && sl < WS_DMA0) || (ROLE == 1 && sl < 32 - WS_DMA0)))
-                ws_dma(c, u, kn1, cur ^ 1, ROLE == 0 ? sl : WS_DMA0 + sl);
+                ws_dma(c, uu, kn1, cur ^ 1, ROLE == 0 ? sl : WS_DMA0 + sl);
+            if (TAIL && ROLE == 0 && sl == 4 * (NP - 1) + 1) ws_setup_lanes(a, c, un, tb ^ 1, Q == 0, vo);
             acc[ws_tab(PS, n, 2)] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][j], bf[set][j], acc[ws_tab(PS, n, 2)], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -273,13 +285,25 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
     f32x16 acc[3];
     f32x4 af[2], bf[2];
     const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    WsUnit u;
+    WsUnit u, un;
     int tb = 0;
 #ifdef WS_STAMPS
     unsigned st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    ws_setup(a, c, x_start + lidl, 0, Q == 0, u, vo);
+    // ---- the workgroup's first unit: first loads, group 0 stages chunk 0, groups 2 and 3 see their DMA of U(0) land (group
+    //      2: and its chunk 2).  Every later unit is staged by the last four K steps of the unit before it ----
+    ws_setup_unit(a, c, x_start + lidl, u);
+    ws_setup_lanes(a, c, u, 0, Q == 0, vo);
     ws_first_loads<Q>(c, u, vo, d);
+    if (Q == 0 || Q == 1) {   // chunks 0 and 1 have no DMA step before their store step
+        ws_rows(d);
+        ws_cols(d);
+    }
+    if (Q == 0) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) ws_store_row(c, d, 0, i);
+    }
+    if (Q == 2 || Q == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (;;) {
         // this unit's bias, now: a load issued in the epilogue would be younger than the next unit's patch loads and its wait
         // would cover them
@@ -288,18 +312,11 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 3; s++) acc[s] = zero16;
-        // ---- prologue: the unit's first loads are already in flight (issued above, or before the previous unit's epilogue);
-        //      group 0 stages chunk 0, groups 2 and 3 see their DMA of U(0) land (group 2: and its chunk 2) ----
-        if (Q == 0 || Q == 1) {   // chunks 0 and 1 have no DMA step before their store step
-            ws_rows(d);
-            ws_cols(d);
-        }
-        if (Q == 0) {
-#pragma unroll
-            for (int i = 0; i < 5; i++) ws_store_row(c, d, 0, i);
-        }
-        if (Q == 2 || Q == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // the next unit (the last unit of a workgroup: itself again, loads of valid memory into staging that nobody reads)
+        const int nl = lidl + per;
+        const bool more = nl < x_count;              // workgroup-uniform
+        ws_setup_unit(a, c, x_start + (more ? nl : lidl), un);
+        __syncthreads();   // chunk 0 is in Vs[0] / Us[0]; every wave is done with the last unit's exchange and tile table
         {
             constexpr int p = 5 * ws_tab(PS, 0, 0) + ws_tab(PS, 0, 1);
             constexpr int um = 4 * ws_umap(ws_tab(PS, 0, 0)) + ws_umap(ws_tab(PS, 0, 1));
@@ -310,29 +327,25 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
 #ifdef WS_STAMPS
         const unsigned tk0 = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-        for (int kc = 0; kc < c.KC; kc += 4) {   // KC % 4 == 0 (Cin % 32 == 0, host-checked)
-            ws_kstep<PS, WN, 0>(c, u, kc, cur, acc, af, bf, d, vo WS_ST_PASS);
-            ws_kstep<PS, WN, 1>(c, u, kc + 1, cur, acc, af, bf, d, vo WS_ST_PASS);
-            ws_kstep<PS, WN, 2>(c, u, kc + 2, cur, acc, af, bf, d, vo WS_ST_PASS);
-            ws_kstep<PS, WN, 3>(c, u, kc + 3, cur, acc, af, bf, d, vo WS_ST_PASS);
+        int kc = 0;
+        for (; kc < c.KC - 4; kc += 4) {   // KC % 4 == 0 (Cin % 32 == 0, host-checked)
+            ws_kstep<PS, WN, 0, false>(a, c, u, un, tb, kc, cur, acc, af, bf, d, vo WS_ST_PASS);
+            ws_kstep<PS, WN, 1, false>(a, c, u, un, tb, kc + 1, cur, acc, af, bf, d, vo WS_ST_PASS);
+            ws_kstep<PS, WN, 2, false>(a, c, u, un, tb, kc + 2, cur, acc, af, bf, d, vo WS_ST_PASS);
+            ws_kstep<PS, WN, 3, false>(a, c, u, un, tb, kc + 3, cur, acc, af, bf, d, vo WS_ST_PASS);
         }
+        ws_kstep<PS, WN, 0, true>(a, c, u, un, tb, kc, cur, acc, af, bf, d, vo WS_ST_PASS);
+        ws_kstep<PS, WN, 1, true>(a, c, u, un, tb, kc + 1, cur, acc, af, bf, d, vo WS_ST_PASS);
+        ws_kstep<PS, WN, 2, true>(a, c, u, un, tb, kc + 2, cur, acc, af, bf, d, vo WS_ST_PASS);
+        ws_kstep<PS, WN, 3, true>(a, c, u, un, tb, kc + 3, cur, acc, af, bf, d, vo WS_ST_PASS);
 #ifdef WS_STAMPS
         st[6] += (unsigned)__builtin_amdgcn_s_memtime() - tk0;
         st[7] += c.KC;
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail loads / DMA have landed
         f32x4 bv4 = {bv, bv, bv, bv};
-        asm volatile("" : "+v"(bv4));   // hipcc's own wait for the bias load goes here, where nothing is in flight
-
-        // ---- the next unit's set-up and first loads go out before this unit's epilogue: d[] and vo[] are free, the first
-        //      staging buffers (Vs[0], Us[0]) were last read a K step ago, the tile table has a second copy ----
+        asm volatile("" : "+v"(bv4));   // hipcc's own wait for the bias load
         const int b0 = u.b0;
-        const int nl = lidl + per;
-        const bool more = nl < x_count;              // workgroup-uniform
-        if (more) {
-            ws_setup(a, c, x_start + nl, tb ^ 1, Q == 0, u, vo);
-            ws_first_loads<Q>(c, u, vo, d);
-        }
+        // (the next unit's chunk 0 is in Vs[0] / Us[0] by now, its chunks 1 and 2 in the registers of groups 1 and 2)
 
         // ---- epilogue.  After the K loop's last barrier nobody reads the second staging buffers any more: the sums another
         //      wave needs are parked there -- slot 1 of every wave (S01, S12, S10, S21) in Us[1] as [wn][q][e / 4][lane] float4,
@@ -369,7 +382,8 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         }
         if (!more) break;
         // no barrier here: the exchange lives in the second staging buffers, which the next unit first writes in its step 0,
-        // after the prologue's barrier; group 0 may stage the next chunk 0 into Vs[0] at once
+        // after the barrier at its top
+        u = un;
         tb ^= 1;
         lidl = nl;
     }
