@@ -414,7 +414,9 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             for (int c = 0; c < cv.cin; c++)
                 for (int t = 0; t < 9; t++) wt[((size_t)t * cv.cin + c) * cv.cout + o] = cv.w[((size_t)o * cv.cin + c) * 9 + t];
         if ((rc = dev_upload(e, &L.d_w, wt)) || (rc = dev_upload(e, &L.d_b, cv.b))) return rc;
-        if (fused_on && l > 0 && cv.stride == 1 && cv.cin % 16 == 0 && cv.cin >= 64 && cv.cin <= fused_max_cin && cv.cout % WF_BN == 0) {
+        // (the fused kernels' tile arithmetic, wf_tile, is exact up to WF_MAX_TDIM tiles a side)
+        const bool tdim_ok = (L.hout + 1) / 2 <= WF_MAX_TDIM && (L.wout + 1) / 2 <= WF_MAX_TDIM;
+        if (fused_on && tdim_ok && l > 0 && cv.stride == 1 && cv.cin % 16 == 0 && cv.cin >= 64 && cv.cin <= fused_max_cin && cv.cout % WF_BN == 0) {
             std::vector<float> u((size_t)16 * cv.cin * cv.cout);
             wf_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
@@ -471,7 +473,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             const int s2f_min_cin = getenv("APR_WINO_S2_FUSED_MIN_CIN") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_CIN")) : 128;
             const int s2f_min_px = getenv("APR_WINO_S2_FUSED_MIN_PX") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_PX")) : 1;
             const int s2f_min_batch = getenv("APR_WINO_S2_FUSED_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_BATCH")) : 128;
-            if (!L.wino && s2f_on && l > 0 && cv.stride == 2 && cv.cin >= s2f_min_cin && cv.cin % 32 == 0 && cv.cout % WS_BN == 0 &&
+            if (!L.wino && s2f_on && tdim_ok && l > 0 && cv.stride == 2 && cv.cin >= s2f_min_cin && cv.cin % 32 == 0 && cv.cout % WS_BN == 0 &&
                 L.hout * L.wout >= s2f_min_px && e->max_batch >= s2f_min_batch) {
                 std::vector<float> u((size_t)16 * cv.cin * cv.cout);
                 ws_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());

@@ -114,6 +114,7 @@ struct WfMagic {
     unsigned long long tiles_n, tpw, tw, th;
     unsigned long long upg_m, gn_m;   // the persistent kernels' unit order (wf_unit): units per N group, N tiles per group
     int upg, gn;
+    unsigned tw16, th16;              // ceil(2^16 / tw), ceil(2^16 / th): divisions of numbers below 2^16 / d (wf_tile)
 };
 __host__ __device__ __forceinline__ int wf_div(int n, unsigned long long m) { return (int)(((unsigned long long)(unsigned)n * m) >> 40); }
 // Unit order of the persistent kernels: N tiles in groups of gn; within a group the units of one M tile follow each other, so
@@ -126,6 +127,26 @@ __host__ __device__ __forceinline__ void wf_unit(int lid, const WfMagic &mg, int
     bm = wf_div(r, mg.gn_m);
     bn = grp * mg.gn + (r - bm * mg.gn);
 }
+// Tile g = (bb * th + ty) * tw + tx of a work unit whose first tile is g0: the unit's first tile is split once (wave-uniform,
+// 40-bit magic numbers), every lane then adds its small tile index t and carries with two 24-bit multiplies
+// (exact while (tw + 64) * tw and (th + 64) * th stay below 2^16: tiles per unit <= 64, th, tw <= WF_MAX_TDIM; host-checked).
+constexpr int WF_MAX_TDIM = 200;
+struct WfUnitBase { int tx0, ty0, bb0; };
+__host__ __device__ __forceinline__ WfUnitBase wf_unit_base(int g0, const WfMagic &mg, int th, int tw)
+{
+    const int rr0 = wf_div(g0, mg.tw), bb0 = wf_div(rr0, mg.th);
+    return WfUnitBase{g0 - rr0 * tw, rr0 - bb0 * th, bb0};
+}
+__host__ __device__ __forceinline__ void wf_tile(const WfUnitBase &ub, int t, const WfMagic &mg, int th, int tw, int &bb, int &ty, int &tx)
+{
+    const unsigned x = (unsigned)(ub.tx0 + t) & 0xFFFFu;
+    const unsigned dq = (x * (mg.tw16 & 0x1FFFFu)) >> 16;
+    tx = (int)(x - dq * ((unsigned)tw & 0xFFFFu));
+    const unsigned y = ((unsigned)ub.ty0 + dq) & 0xFFFFu;
+    const unsigned db = (y * (mg.th16 & 0x1FFFFu)) >> 16;
+    ty = (int)(y - db * ((unsigned)th & 0xFFFFu));
+    bb = ub.bb0 + (int)db;
+}
 // tiles_m has no default on purpose: a unit order built for another M extent sends units to N tiles that do not exist
 inline WfMagic wf_magic(int tiles_n, int th, int tw, long long tiles_m, int gn = 0)
 {
@@ -133,7 +154,7 @@ inline WfMagic wf_magic(int tiles_n, int th, int tw, long long tiles_m, int gn =
     if (gn < 1 || gn > tiles_n) gn = tiles_n;
     while (tiles_n % gn) gn--;           // a divisor of tiles_n
     const long long upg = tiles_m * gn;
-    return WfMagic{mk(tiles_n), mk((long long)th * tw), mk(tw), mk(th), mk(upg), mk(gn), (int)upg, gn};
+    return WfMagic{mk(tiles_n), mk((long long)th * tw), mk(tw), mk(th), mk(upg), mk(gn), (int)upg, gn, (65536u + (unsigned)tw - 1) / (unsigned)tw, (65536u + (unsigned)th - 1) / (unsigned)th};
 }
 
 // in  [B][H][W][Cin] ; up = packed U (wf_pack_u) ; out [B][H][W][Cout] = relu(conv + bias)

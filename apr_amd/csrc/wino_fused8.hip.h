@@ -75,6 +75,7 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     const int dma_wave = __builtin_amdgcn_readfirstlane(wave < 4 ? 1 : 0);
     const int ph = wave & 1;                    // which 8 of the 16 positions; also the staging parity
     const int sub = wave >> 1;                  // the pair: 2 (tiles) x 2 (channels)
+    const int subs = __builtin_amdgcn_readfirstlane(wave >> 1);
     const int wm = sub >> 1, wn = sub & 1;
     const int li = lane & 31, half = lane >> 5;
     const int sid = sub * 64 + lane;            // 0..255 among the four waves of one parity
@@ -95,22 +96,26 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
     // tile table TB_ (zero padding = out-of-range buffer offsets)
 #define W8_SETUP(LID_, TB_, BN_, B0_, VOFF_, VMASK_)                                                     \
     {                                                                                                    \
+        /* the lane's tile and channel pair, from scratch: kept in registers across the K loop they are spilled */ \
+        unsigned ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));               \
+        asm volatile("" : "+v"(ln_));                                                                    \
+        const int sid_ = subs * 64 + (int)ln_, t_ld_ = sid_ >> 2, cp_ = sid_ & 3;                        \
         int bm_;                                                                                         \
         wf_unit((LID_), mg, bm_, BN_);                                                                   \
         const int g0_ = bm_ * WF_TT;                                                                     \
         B0_ = wf_div(g0_, mg.tpw);                                                                       \
         VOFF_ = OOB; VMASK_ = 0;                                                                         \
         u32x4 to_ = {OOB, OOB, OOB, OOB};                                                                \
-        const int g_ = g0_ + t_ld;                                                                       \
+        const int g_ = g0_ + t_ld_;                                                                       \
+        const WfUnitBase ub_ = wf_unit_base(g0_, mg, th, tw);   /* wave-uniform */                       \
         if (g_ < T) {                                                                                    \
-            const int rr_ = wf_div(g_, mg.tw);                                                           \
-            const int tx_ = g_ - rr_ * tw;                                                               \
-            const int bb_ = wf_div(rr_, mg.th);                                                          \
-            const int ty_ = rr_ - bb_ * th;                                                              \
+            int bb_, ty_, tx_;                                                                           \
+            wf_tile(ub_, t_ld_, mg, th, tw, bb_, ty_, tx_);                                               \
             const int db_ = bb_ - B0_;                                                                   \
-            const int y0_ = 2 * ty_ - 1, x0_ = 2 * tx_ - 1;                                              \
-            VOFF_ = 4u * (unsigned)(((db_ * H + y0_ + 1) * W + x0_ + 1) * Cin + 2 * cp);                 \
-            const unsigned o00_ = 4u * (unsigned)(((db_ * H + 2 * ty_) * W + 2 * tx_) * Cout);           \
+            /* the tile's first output pixel, which is also pixel (1, 1) of its patch; every factor is below 2^24 */ \
+            const unsigned pix_ = ((unsigned)(db_ * H + 2 * ty_) & 0xFFFFFFu) * ((unsigned)W & 0xFFFFFFu) + 2u * (unsigned)tx_; \
+            VOFF_ = 4u * ((pix_ & 0xFFFFFFu) * ((unsigned)Cin & 0xFFFFFFu) + 2u * (unsigned)cp_);         \
+            const unsigned o00_ = 4u * ((pix_ & 0xFFFFFFu) * ((unsigned)Cout & 0xFFFFFFu));              \
             const bool r1_ = 2 * ty_ + 1 < H, c1_ = 2 * tx_ + 1 < W;                                     \
             to_.x = o00_;                                                                                \
             to_.y = c1_ ? o00_ + 4u * (unsigned)Cout : OOB;                                              \
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
             const unsigned colok_ = (tx_ > 0 ? 1u : 0u) | 2u | (2 * tx_ + 1 < W ? 4u : 0u) | (2 * tx_ + 2 < W ? 8u : 0u); \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) VMASK_ |= ((rowok_ >> i_) & 1u) ? colok_ << (4 * i_) : 0u; \
         }                                                                                                \
-        if (cp == 0 && ph == 0) *reinterpret_cast<u32x4 *>(tbl + (TB_) * 256 + 4 * t_ld) = to_;          \
+        if (cp_ == 0 && phs == 0) *reinterpret_cast<u32x4 *>(tbl + (TB_) * 256 + 4 * t_ld_) = to_;          \
     }
     // descriptors of a unit: its window's image (one row and one column early, so every valid tap has a
     // non-negative offset) and its N tile's U image

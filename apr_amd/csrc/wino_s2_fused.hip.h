@@ -128,11 +128,10 @@ __device__ __forceinline__ void ws_setup_lanes(const WsArgs &a, const WsCtx &c, 
     unsigned voff = OOB, vmask = 0;
     u32x4 to = {OOB, OOB, OOB, OOB};
     const int g = u.g0 + c.t_ld;
+    const WfUnitBase ub = wf_unit_base(u.g0, a.mg, a.th, a.tw);   // wave-uniform
     if (g < a.T) {
-        const int rr = wf_div(g, a.mg.tw);
-        const int tx = g - rr * a.tw;
-        const int bb = wf_div(rr, a.mg.th);
-        const int ty = rr - bb * a.th;
+        int bb, ty, tx;
+        wf_tile(ub, c.t_ld, a.mg, a.th, a.tw, bb, ty, tx);
         const int db = bb - u.b0;
         // patch = input rows 4ty-1 .. 4ty+3, columns 4tx-1 .. 4tx+3; the descriptor starts one row and one column early
         voff = 4u * (unsigned)(((db * a.H + 4 * ty) * a.W + 4 * tx) * a.Cin + 2 * c.cp);

@@ -339,6 +339,22 @@ int main()
         }
         for (int v : seen) if (v != 1) { printf("not a bijection\n"); return 1; }
     }
+    // wf_unit_base + wf_tile: a unit's first tile split once, its lanes' tiles by small-number arithmetic -- against plain division
+    const int shapes[][2] = {{32, 47}, {16, 24}, {8, 12}, {4, 6}, {2, 3}, {1, 2}, {64, 94}, {1, 1}, {3, 200}, {200, 1}, {199, 197}, {5, 7}};
+    for (auto &sh : shapes) {
+        const int th = sh[0], tw = sh[1];
+        const apr::WfMagic mg = apr::wf_magic(2, th, tw, 1000, 0);
+        const long long total = (long long)th * tw * 2048;
+        for (long long g0 = 0; g0 < total; g0 += (g0 < 70000 ? 32 : 32 * 977)) {
+            const apr::WfUnitBase ub = apr::wf_unit_base((int)g0, mg, th, tw);
+            for (int t = 0; t < 64; t++) {
+                int bb, ty, tx;
+                apr::wf_tile(ub, t, mg, th, tw, bb, ty, tx);
+                const long long g = g0 + t, rr = g / tw;
+                if (tx != g % tw || ty != rr % th || bb != rr / th) { printf("tile %lld of %dx%d wrong\n", g, th, tw); return 1; }
+            }
+        }
+    }
     printf("ok\n");
     return 0;
 }
