@@ -29,9 +29,9 @@
 //              group (k+1)%4 stores chunk k+1 and DMAs 12 KiB of U(k+1) | group k%4 DMAs 20 KiB of U(k+1)
 // (a DMA wave waits vmcnt(0) before the step's barrier: nothing else of its own is in flight then)
 // The K loop is unrolled by four, so a wave's role in every step is a compile-time constant of its code path (one path
-// per q).  Workgroups are persistent (one per CU, the units cut into 8 XCD-contiguous runs): after a unit's K loop the next
-// unit's tile table, patch offsets, first patch loads (chunks 0 and 1) and first U DMA go out, so their latency runs under
-// the epilogue.  Epilogue: the sums that another wave needs (S01, S12, S10, S21, S11) are parked in the second staging
+// per q).  Workgroups are persistent (one per CU, the units cut into 8 XCD-contiguous runs) and the staging pipeline runs on
+// across the unit boundary: the last four K steps of a unit (ws_kstep<..., TAIL>) fetch chunks 0, 1, 2 and U(0) of the
+// workgroup's next unit, each group turning its patch offsets to that unit in its idle step of the four.  Epilogue: the sums that another wave needs (S01, S12, S10, S21, S11) are parked in the second staging
 // buffers, one barrier, then wave q = 2a + b forms output pixel (a, b) of each tile,
 //     Y[a][b] = (S[a][b] + S[a+1][b]) + (S[a][b+1] + S[a+1][b+1]) + bias, ReLU, NHWC store through the tile table.
 #pragma once
