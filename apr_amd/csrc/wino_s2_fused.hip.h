@@ -76,7 +76,7 @@ __host__ __device__ constexpr int ws_tab(int ps, int n, int f)
 __host__ __device__ constexpr int ws_umap(int p) { return p < 3 ? p : 3; }            // U = [w0, w0 + w2, w2, w1, w1]
 
 #ifdef WS_STAMPS   // developer build (tools/ws_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles waited at the barrier
-                   // of the steps of each phase, K loop total, steps
+                   // of the steps of each phase [0..3], epilogue [4], top of a unit [5], K loop total [6], steps [7]
 __device__ unsigned long long ws_stamps[8][8];
 #define WS_ST_ARG , unsigned (&st)[8]
 #define WS_ST_PASS , st
@@ -309,6 +309,9 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         const int n = u.bn * WS_BN + wn * 32 + li;
         const float bv = a.bias[n];
         __builtin_amdgcn_sched_barrier(0);
+#ifdef WS_STAMPS
+        const unsigned tu0 = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int s = 0; s < 3; s++) acc[s] = zero16;
         // the next unit (the last unit of a workgroup: itself again, loads of valid memory into staging that nobody reads)
@@ -325,6 +328,7 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         int cur = 0;
 #ifdef WS_STAMPS
         const unsigned tk0 = (unsigned)__builtin_amdgcn_s_memtime();
+        st[5] += tk0 - tu0;                          // top of the unit: clear, next unit's scalars, barrier, first operands
 #endif
         int kc = 0;
         for (; kc < c.KC - 4; kc += 4) {   // KC % 4 == 0 (Cin % 32 == 0, host-checked)
@@ -338,7 +342,8 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
         ws_kstep<PS, WN, 2, true>(a, c, u, un, tb, kc + 2, cur, acc, af, bf, d, vo WS_ST_PASS);
         ws_kstep<PS, WN, 3, true>(a, c, u, un, tb, kc + 3, cur, acc, af, bf, d, vo WS_ST_PASS);
 #ifdef WS_STAMPS
-        st[6] += (unsigned)__builtin_amdgcn_s_memtime() - tk0;
+        const unsigned tk1 = (unsigned)__builtin_amdgcn_s_memtime();
+        st[6] += tk1 - tk0;
         st[7] += c.KC;
 #endif
         f32x4 bv4 = {bv, bv, bv, bv};
@@ -379,6 +384,9 @@ __device__ __forceinline__ void ws_run(const WsArgs &a, const WsCtx &c, int x_st
                 wf_store1(rsO, o + nb4, wf_relu(y[r]));
             }
         }
+#ifdef WS_STAMPS
+        st[4] += (unsigned)__builtin_amdgcn_s_memtime() - tk1;   // the epilogue, stores issued
+#endif
         if (!more) break;
         // no barrier here: the exchange lives in the second staging buffers, which the next unit first writes in its step 0,
         // after the barrier at its top

@@ -255,13 +255,13 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
     want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
     blob = W.pack_blob(he_weights, 4)
 
-    def run(env, batch=8):
+    def run(env, batch=8, x=specs):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         e = model.Engine(blob, 0, batch)
         for k in env:
             monkeypatch.delenv(k)
-        out = e.infer_logits(specs)
+        out = e.infer_logits(x)
         e.close()
         return out
 
@@ -286,6 +286,12 @@ def test_direct_and_winograd_paths_agree(he_weights, monkeypatch):
     ref = run({"APR_WINO_FUSED_MAX_CIN": "512", **s2f})
     for gn in ("1", "2", "64"):
         assert np.array_equal(ref, run({"APR_WINO_FUSED_MAX_CIN": "512", "APR_WINO_GN": gn, "APR_WINO_S2_GN": gn, **s2f}))
+    # Long runs of units per workgroup: the K loop of a unit stages the first chunks of the workgroup's next unit, tile
+    # tables and exchange buffers alternate.  100 clips in one pass = 18 units per workgroup on layer 3, 3 on layer 7, a
+    # ragged last unit on every layer -- bit for bit what the 8-clip engine (one or two units per workgroup) computes.
+    many = np.concatenate([specs] * 17)[:100]
+    big = run({"APR_WINO_FUSED_MAX_CIN": "512", **s2f}, batch=100, x=many)
+    assert np.array_equal(big[:6], ref) and np.array_equal(big[96:100], ref[:4]) and np.array_equal(big[48:54], ref)
 
 
 def test_stride2_polyphase_winograd_layers(he_weights, monkeypatch):

@@ -23,3 +23,9 @@ print("wave(wn*4+q): barrier wait cycles per step of phase (approx.: every phase
 for w in range(8):
     u = max(a[w, 7], 1)
     print(w, " ".join(f"{NPH * x / u:7.0f}" for x in a[w, :NPH]), "|", f"{a[w, 6] / u:7.0f}", "|", int(a[w, 7]))
+if os.environ.get("WS_KC"):   # one stamped layer (e.g. APR_WINO_S2_FUSED_MIN_PX=1000: layer 4 alone, WS_KC=16): cycles per unit
+    kc = int(os.environ["WS_KC"])
+    print("per unit: epilogue | top of unit | K loop")
+    for w in range(8):
+        units = max(a[w, 7] / kc, 1)
+        print(w, f"{a[w, 4] / units:7.0f} {a[w, 5] / units:7.0f} {a[w, 6] / units:7.0f}")
