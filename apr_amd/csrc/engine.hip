@@ -1521,20 +1521,25 @@ static int sweep_files_on(apr_engine *e, const int *idx, int n_idx, const uint8_
 
     // segments: [w0, w0 + nw) of one file, laid into a pass at a stride-aligned base; the span_w - 1
     // stream windows after a segment straddle into the next one and are dropped
+    // The first passes are short (512 windows, then twice as many each time up to max_batch): the staging copy and H2D of the
+    // first pass have nothing to hide behind, every later one runs under the pass before it (staging 2 k windows takes about
+    // as long as computing 500).  Pass sizes are bit-invisible (GPU tests).
     struct Seg { int file; size_t w0, nw, base_w, row; };
     std::vector<std::vector<Seg>> passes(1);
+    auto cap_of = [&](size_t p) { return std::min(cap_w, std::max(span_w, p < 8 ? (size_t)512 << p : cap_w)); };
     size_t used = 0;
     for (int i = 0; i < n_idx; i++) {
         const int f = idx ? idx[i] : i;
         if (nbytes[f] && !pcm[f]) { e->err = "apr_sweep_files: NULL recording with a non-zero length"; return APR_ERR_INVALID; }
         size_t W = apr_windows_in(nbytes[f], stride_bytes), w0 = 0, row = row_base[f];
         while (W) {
-            const size_t room = cap_w - used;
+            const size_t cap_p = cap_of(passes.size() - 1);
+            const size_t room = cap_p > used ? cap_p - used : 0;
             if (room < 1) { passes.emplace_back(); used = 0; continue; }
             const size_t nw = std::min(W, room);
             passes.back().push_back({f, w0, nw, used, row});
-            used += nw + span_w - 1;       // next base; may pass cap_w: those windows are not computed
-            if (used >= cap_w) { passes.emplace_back(); used = 0; }
+            used += nw + span_w - 1;       // next base; may pass the cap: those windows are not computed
+            if (used >= cap_p) { passes.emplace_back(); used = 0; }
             w0 += nw; W -= nw; row += nw;
         }
     }

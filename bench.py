@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--files", type=int, default=60, help="config 2: recordings per GPU")
     ap.add_argument("--hours", type=float, default=1000.0, help="config 3: hours of audio in the whole job")
     ap.add_argument("--seconds", type=int, default=600, help="seconds per recording")
-    ap.add_argument("--max-batch", type=int, default=2048, help="windows per GPU pass")
+    ap.add_argument("--max-batch", type=int, default=4096, help="windows per GPU pass")
     ap.add_argument("--cpu-windows", type=int, default=599, help="windows of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true",

@@ -7,7 +7,7 @@ cd $R
 for gn in $1; do
   export APR_WINO_GN=$gn APR_WINO_S2_GN=$gn
   rm -rf gpurun_out/gn_f
-  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/gn_f -o p -- python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 1025 > gpurun_out/gn_f.out 2>&1 || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/gn_f -o p -- python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 2049 > gpurun_out/gn_f.out 2>&1 || exit 1
   timeout -k 10 200 python3 bench.py --no-extras --steps 2 > gpurun_out/gn_t.json 2>/dev/null || exit 1
   python3 - <<PY
 import csv, collections, json
@@ -18,6 +18,6 @@ for r in csv.DictReader(open('gpurun_out/gn_f/p_counter_collection.csv')):
 ks=sorted(k for k in f if 'wino' in k[1])[:10]
 d=json.loads([l for l in open('gpurun_out/gn_t.json').read().splitlines() if l.startswith('{')][-1])
 ms={l['layer']:l['ms_per_step'] for l in d['layers']}
-print('gn=$gn', round(d['ms_per_step'],1), ' '.join(f"L{l}:{f[k]*2048/1e9:.2f}GB/{ms[l]:.1f}ms" for k,l in zip(ks,range(3,13))))
+print('gn=$gn', round(d['ms_per_step'],1), ' '.join(f"L{l}:{f[k]*4096/1e9:.2f}GB/{ms[l]:.1f}ms" for k,l in zip(ks,range(3,13))))
 PY
 done

@@ -3,7 +3,7 @@
 into per-kernel HBM traffic per launch.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- \
-        python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 1025
+        python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 2049
     rocprofv3 --pmc WRITE_SIZE ... -d gpurun_out/pmc_write ...
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
 
