@@ -378,6 +378,18 @@ def test_sweep_files_equals_per_file_score(he_weights):
     assert np.array_equal(again["probs"], got["probs"][:7])
     assert eng.sweep_files([], trust=0.4)["label"].shape == (0,)
     eng.close()
+    # An engine of more than 512 windows starts a sweep with short passes (512 windows, then 1024, ...): 2 100 windows in three
+    # recordings = passes of 512 / 1024 / 564, a recording split at both pass boundaries -- equal to its own score() bit for bit
+    eng = model.Engine(W.pack_blob(he_weights, 4), 0, 1024)
+    files = [model.synth_pcm(5, i, s) for i, s in enumerate((301, 1500, 302))]
+    got = eng.sweep_files(files, trust=0.4, empty_class=2)
+    assert got["label"].shape == (300 + 1499 + 301,)
+    for i, f in enumerate(files):
+        a, b = got["first_window"][i], got["first_window"][i + 1]
+        want = eng.score(f, b - a, trust=0.4, empty_class=2)
+        assert np.array_equal(got["probs"][a:b], want["probs"]) and np.array_equal(got["label"][a:b], want["label"])
+        assert np.array_equal(got["match"][a:b], want["match"])
+    eng.close()
 
 
 def test_latency_engine_split_k(he_weights):
