@@ -38,6 +38,9 @@ __device__ unsigned long long w8_ksteps[8][8];     // cycles per K step: the two
 #define W8_US(I_)
 #define W8_UK(I_)
 #endif
+#ifdef W8_TIMES    // developer build (tools/wino_fused_bench.cpp): s_memrealtime (100 MHz, one clock for the chip) at the first and last instruction of every workgroup
+__device__ unsigned long long w8_times[1024][2];
+#endif
 #ifdef W8_STAMPS   // developer build (tools/ws_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles waited at the barrier of
                    // its load steps [0] / store steps [1], K loop total [6], steps [7]
 __device__ unsigned long long w8_stamps[8][8];
@@ -64,6 +67,9 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = tid >> 6;
+#ifdef W8_TIMES
+    if (tid == 0) w8_times[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int phs = __builtin_amdgcn_readfirstlane(wave & 1);    // ph as a scalar: the epilogue branches on it instead of selecting per lane
     // Waves w and w + 4 share a SIMD, and the SIMD serves the older one (w < 4) first: its staging instructions run beside
     // the other wave's MFMAs, the other wave's own are exposed (wino_s2_fused.hip.h, tools/ws_stamps.py).  The U DMA is
@@ -446,6 +452,9 @@ __global__ __launch_bounds__(512) void wino_fused8_f2(const float *__restrict__ 
 #ifdef W8_STAMPS
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; i++) w8_stamps[wave][i] += st8[i];
+#endif
+#ifdef W8_TIMES
+    if (tid == 0) w8_times[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef W8_USTAMPS
     if (blockIdx.x == 0 && lane == 0)

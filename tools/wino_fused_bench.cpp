@@ -144,6 +144,24 @@ int main(int argc, char **argv)
         }
     }
 #endif
+#ifdef W8_TIMES
+    {
+        static unsigned long long h[1024][2];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(apr::w8_times), sizeof h));
+        const int g = (int)apr::wf8_grid((int)(tiles_m * tiles_n), n_cus);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int b = 0; b < g; b++) { t0 = std::min(t0, h[b][0]); t1 = std::max(t1, h[b][1]); }
+        printf("last launch: %d workgroups, %.1f us from the first start to the last end (100 MHz ticks)\n", g, (double)(t1 - t0) / 100.0);
+        for (int x = 0; x < 8; x++) {
+            double s0 = 1e30, s1 = 0, e0 = 1e30, e1 = 0;
+            for (int b = x; b < g; b += 8) {
+                s0 = std::min(s0, (double)(h[b][0] - t0)); s1 = std::max(s1, (double)(h[b][0] - t0));
+                e0 = std::min(e0, (double)(h[b][1] - t0)); e1 = std::max(e1, (double)(h[b][1] - t0));
+            }
+            printf("  XCD %d: starts %.1f .. %.1f us, ends %.1f .. %.1f us\n", x, s0 / 100, s1 / 100, e0 / 100, e1 / 100);
+        }
+    }
+#endif
     if (argc > 7) return 0;   // timing-only ablation builds
     return std::isfinite(stat[0]) && stat[0] <= 1e-4f * fmaxf(stat[1], 1.0f) ? 0 : 2;
 }
