@@ -3,8 +3,16 @@
 // Replaces onnx-go's `UnmarshalBinary` for the one graph family the reference exports
 // (src/model/model.go:190-196 unmarshals it on EVERY Infer call; here it runs once per
 // engine).  Accepted graph: [Conv(3x3, pads 1, stride 1|2) -> optional BatchNormalization
-// -> Relu] x L, GlobalMaxPool, Flatten, Gemm -- i.e. ai/model.py:55-110 in eval mode, with
-// BatchNorm either folded by the exporter or left as explicit nodes.
+// -> Relu] x L, the global max pool, Flatten, Gemm -- i.e. ai/model.py:55-110 in eval mode,
+// with BatchNorm either folded by the exporter or left as explicit nodes.
+//
+// The global pool: ai/model.py:106 is AdaptiveMaxPool2d(1).  The exporter the reference
+// calls (ai/model.py:149-152: legacy TorchScript exporter, static 1x1x128x188 input) writes
+// it as MaxPool(kernel_shape = the last conv's whole output map = [2,3], strides [2,3],
+// pads 0) -- see tests/golden/onnx_real_export.json, the structure of a real export.
+// GlobalMaxPool is what the same exporter writes when the map size is unknown; both are
+// accepted, and a MaxPool that is anything but the whole map is rejected with the reason.
+// The node list must be one chain: every node consumes the previous node's output.
 #include "model_parse.h"
 
 #include <cmath>
@@ -77,7 +85,11 @@ struct Node {
     std::map<std::string, std::vector<int64_t>> ints;
     std::map<std::string, int64_t> i;
     std::map<std::string, float> f;
+    std::map<std::string, std::string> s;
 };
+
+// the engine's fixed input map (src/model/model.go:33,36: Nmels x SpectrogramFrames)
+constexpr int kInH = 128, kInW = 188;
 
 bool parse_tensor(Reader r, std::string &name, Tensor &t)
 {
@@ -103,7 +115,8 @@ bool parse_attr(Reader r, Node &n)
 {
     std::string name;
     std::vector<int64_t> ints;
-    bool has_i = false, has_f = false;
+    bool has_i = false, has_f = false, has_s = false;
+    std::string sv;
     int64_t iv = 0;
     float fv = 0;
     while (!r.done()) {
@@ -111,6 +124,7 @@ bool parse_attr(Reader r, Node &n)
         if (f == 1 && wt == 2) name = r.str();
         else if (f == 2 && wt == 5) { if (r.end - r.p < 4) return false; memcpy(&fv, r.p, 4); r.p += 4; has_f = true; }
         else if (f == 3 && wt == 0) { iv = (int64_t)r.varint(); has_i = true; }
+        else if (f == 4 && wt == 2) { sv = r.str(); has_s = true; }
         else if (f == 8 && wt == 0) ints.push_back((int64_t)r.varint());
         else if (f == 8 && wt == 2) { Reader s = r.sub(); while (!s.done()) ints.push_back((int64_t)s.varint()); }
         else r.skip(wt);
@@ -119,6 +133,7 @@ bool parse_attr(Reader r, Node &n)
     if (!ints.empty()) n.ints[name] = ints;
     if (has_i) n.i[name] = iv;
     if (has_f) n.f[name] = fv;
+    if (has_s) n.s[name] = sv;
     return true;
 }
 
@@ -135,6 +150,50 @@ bool parse_node(Reader r, Node &n)
     return r.ok;
 }
 
+// ValueInfoProto{1 name, 2 TypeProto{1 Tensor{2 TensorShapeProto{1 Dimension{1 dim_value | 2 dim_param}}}}}; a symbolic dim reads as -1
+bool parse_value_info(Reader r, std::string &name, std::vector<int64_t> &dims)
+{
+    while (!r.done()) {
+        int wt, f = r.key(wt);
+        if (f == 1 && wt == 2) name = r.str();
+        else if (f == 2 && wt == 2) {
+            Reader ty = r.sub();
+            while (!ty.done()) {
+                int wt2, f2 = ty.key(wt2);
+                if (f2 == 1 && wt2 == 2) {
+                    Reader tt = ty.sub();
+                    while (!tt.done()) {
+                        int wt3, f3 = tt.key(wt3);
+                        if (f3 == 2 && wt3 == 2) {
+                            Reader sh = tt.sub();
+                            while (!sh.done()) {
+                                int wt4, f4 = sh.key(wt4);
+                                if (f4 == 1 && wt4 == 2) {
+                                    Reader d = sh.sub();
+                                    int64_t v = -1;
+                                    while (!d.done()) { int wt5, f5 = d.key(wt5); if (f5 == 1 && wt5 == 0) v = (int64_t)d.varint(); else d.skip(wt5); }
+                                    if (!d.ok) return false;
+                                    dims.push_back(v);
+                                } else sh.skip(wt4);
+                            }
+                            if (!sh.ok) return false;
+                        } else tt.skip(wt3);
+                    }
+                    if (!tt.ok) return false;
+                } else ty.skip(wt2);
+            }
+            if (!ty.ok) return false;
+        } else r.skip(wt);
+    }
+    return r.ok;
+}
+
+bool all_equal(const std::vector<int64_t> &v, int64_t x)
+{
+    for (auto e : v) if (e != x) return false;
+    return true;
+}
+
 bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::string &err)
 {
     Reader m(bytes, nbytes);
@@ -148,6 +207,7 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
     if (!m.ok || !gp) { err = "not an ONNX ModelProto (no graph)"; return false; }
     std::vector<Node> nodes;
     std::map<std::string, Tensor> inits;
+    std::map<std::string, std::vector<int64_t>> graph_inputs;
     Reader g(gp, gn);
     while (!g.done()) {
         int wt, f = g.key(wt);
@@ -156,6 +216,10 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
             std::string name; Tensor t;
             if (!parse_tensor(g.sub(), name, t)) { err = "bad TensorProto"; return false; }
             if (t.dtype == 1) inits[name] = std::move(t);
+        } else if (f == 11 && wt == 2) {
+            std::string name; std::vector<int64_t> dims;
+            if (!parse_value_info(g.sub(), name, dims)) { err = "bad ValueInfoProto"; return false; }
+            graph_inputs[name] = std::move(dims);
         } else g.skip(wt);
     }
     if (!g.ok) { err = "truncated ONNX graph"; return false; }
@@ -170,11 +234,33 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
 
     size_t i = 0;
     bool seen_pool = false, seen_gemm = false;
+    int map_h = kInH, map_w = kInW;      // output map of the conv chain so far, at the engine's input size
+    std::string cur;                     // name of the value the chain has produced so far ("" before the first node)
+    // one chain: node i reads what node i-1 wrote (a graph with a branch or a skipped value would otherwise be
+    // accepted and scored as a different function)
+    auto follows = [&](const Node &n) -> bool {
+        if (n.in.empty() || n.out.empty() || n.out[0].empty()) { err = "node '" + n.op + "' has no input or output"; return false; }
+        if (!cur.empty() && n.in[0] != cur) { err = "graph is not one chain: '" + n.op + "' reads '" + n.in[0] + "', the previous node wrote '" + cur + "'"; return false; }
+        return true;
+    };
     while (i < nodes.size()) {
         const Node &n = nodes[i];
+        if (seen_gemm && n.op != "Constant") { err = "node '" + n.op + "' after the classifier Gemm"; return false; }
         if (n.op == "Conv") {
-            if (seen_pool) { err = "Conv after GlobalMaxPool"; return false; }
+            if (seen_pool) { err = "Conv after the global max pool"; return false; }
             if (n.in.size() < 2) { err = "Conv without weights"; return false; }
+            if (!follows(n)) return false;
+            if (cur.empty()) {
+                // the data input: when the graph declares its shape it must be the engine's [N,1,128,188] (ai/model.py:150)
+                auto gi = graph_inputs.find(n.in[0]);
+                if (gi != graph_inputs.end() && !gi->second.empty()) {
+                    const auto &d = gi->second;
+                    if (d.size() != 4 || (d[1] >= 0 && d[1] != 1) || (d[2] >= 0 && d[2] != kInH) || (d[3] >= 0 && d[3] != kInW)) {
+                        err = "model input '" + n.in[0] + "' is not [N,1," + std::to_string(kInH) + "," + std::to_string(kInW) + "]: the engine scores 128x188 spectrograms only";
+                        return false;
+                    }
+                }
+            }
             const Tensor *w = nullptr;
             if (!get(n.in[1], 0, w)) return false;
             if (w->dims.size() != 4 || w->dims[2] != 3 || w->dims[3] != 3) { err = "Conv kernel is not 3x3"; return false; }
@@ -184,6 +270,10 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
             c.cout = (int)w->dims[0];
             c.cin = (int)w->dims[1];
             if (w->data.size() != (size_t)c.cout * c.cin * 9) { err = "Conv weight size mismatch"; return false; }
+            auto ks = n.ints.find("kernel_shape");
+            if (ks != n.ints.end() && (ks->second.size() != 2 || ks->second[0] != 3 || ks->second[1] != 3)) { err = "Conv kernel_shape is not [3,3]"; return false; }
+            auto ap = n.s.find("auto_pad");
+            if (ap != n.s.end() && ap->second != "NOTSET") { err = "Conv auto_pad '" + ap->second + "' unsupported"; return false; }
             auto st = n.ints.find("strides");
             c.stride = (st != n.ints.end() && !st->second.empty()) ? (int)st->second[0] : 1;
             if (st != n.ints.end() && st->second.size() == 2 && st->second[0] != st->second[1]) { err = "anisotropic stride"; return false; }
@@ -200,10 +290,13 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
                 if (!get(n.in[2], (size_t)c.cout, b)) return false;
                 c.b = b->data;
             }
+            cur = n.out[0];
             i++;
             if (i < nodes.size() && nodes[i].op == "BatchNormalization") {
                 const Node &bn = nodes[i];
                 if (bn.in.size() < 5) { err = "BatchNormalization needs 5 inputs"; return false; }
+                if (!follows(bn)) return false;
+                cur = bn.out[0];
                 const Tensor *g2, *be, *mu, *va;
                 if (!get(bn.in[1], c.cout, g2) || !get(bn.in[2], c.cout, be) || !get(bn.in[3], c.cout, mu) || !get(bn.in[4], c.cout, va)) return false;
                 auto ep = bn.f.find("epsilon");
@@ -216,13 +309,55 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
                 i++;
             }
             if (i >= nodes.size() || nodes[i].op != "Relu") { err = "Conv block without Relu"; return false; }
+            if (!follows(nodes[i])) return false;
+            cur = nodes[i].out[0];
             i++;
+            if (c.stride == 1 || c.stride == 2) { map_h = (map_h + 2 - 3) / c.stride + 1; map_w = (map_w + 2 - 3) / c.stride + 1; }
             out.convs.push_back(std::move(c));
-        } else if (n.op == "GlobalMaxPool") { seen_pool = true; i++; }
-        else if (n.op == "Flatten" || n.op == "Reshape" || n.op == "Dropout" || n.op == "Identity" || n.op == "Constant" || n.op == "Squeeze") { i++; }
+        } else if (n.op == "GlobalMaxPool" || n.op == "MaxPool") {
+            if (seen_pool) { err = "second pooling node"; return false; }
+            if (out.convs.empty()) { err = "pooling before the first Conv"; return false; }
+            if (!follows(n)) return false;
+            if (n.op == "MaxPool") {
+                // only the whole-map pool is the reference's AdaptiveMaxPool2d(1) (ai/model.py:106); anything else is another network
+                const std::string want = "[" + std::to_string(map_h) + "," + std::to_string(map_w) + "]";
+                auto ks = n.ints.find("kernel_shape");
+                if (ks == n.ints.end() || ks->second.size() != 2 || ks->second[0] != map_h || ks->second[1] != map_w) {
+                    std::string got = "none";
+                    if (ks != n.ints.end()) { got = "["; for (size_t q = 0; q < ks->second.size(); q++) got += (q ? "," : "") + std::to_string(ks->second[q]); got += "]"; }
+                    err = "MaxPool kernel_shape " + got + " is not the last conv's whole " + want + " output map (only the global pool of AdaptiveMaxPool2d(1) is supported)";
+                    return false;
+                }
+                auto pd = n.ints.find("pads");
+                if (pd != n.ints.end() && !all_equal(pd->second, 0)) { err = "MaxPool with padding is not a global pool"; return false; }
+                auto dl = n.ints.find("dilations");
+                if (dl != n.ints.end() && !all_equal(dl->second, 1)) { err = "dilated MaxPool unsupported"; return false; }
+                auto st = n.ints.find("strides");
+                if (st != n.ints.end()) for (auto v : st->second) if (v < 1) { err = "MaxPool stride < 1"; return false; }
+                auto ap = n.s.find("auto_pad");
+                if (ap != n.s.end() && ap->second != "NOTSET" && ap->second != "VALID") { err = "MaxPool auto_pad '" + ap->second + "' unsupported"; return false; }
+                auto so = n.i.find("storage_order");
+                if (so != n.i.end() && so->second != 0) { err = "MaxPool storage_order unsupported"; return false; }
+                // ceil_mode cannot add an output when the kernel covers the whole unpadded map: ignored
+                if (n.out.size() > 1 && !n.out[1].empty()) { err = "MaxPool Indices output unsupported"; return false; }
+            }
+            seen_pool = true;
+            cur = n.out[0];
+            i++;
+        }
+        else if (n.op == "Constant") { i++; }     // a side input (Reshape's shape): not part of the chain
+        else if (n.op == "Flatten" || n.op == "Reshape" || n.op == "Dropout" || n.op == "Identity" || n.op == "Squeeze") {
+            if (!follows(n)) return false;
+            if (!seen_pool) { err = "'" + n.op + "' before the global max pool"; return false; }
+            cur = n.out[0];
+            i++;
+        }
         else if (n.op == "Gemm") {
-            if (!seen_pool) { err = "Gemm before GlobalMaxPool"; return false; }
+            if (!seen_pool) { err = "Gemm before the global max pool"; return false; }
             if (n.in.size() < 2) { err = "Gemm without weights"; return false; }
+            if (!follows(n)) return false;
+            auto ta = n.i.find("transA");
+            if (ta != n.i.end() && ta->second != 0) { err = "Gemm transA unsupported"; return false; }
             const Tensor *w = nullptr;
             if (!get(n.in[1], 0, w)) return false;
             if (w->dims.size() != 2) { err = "Gemm weight is not 2-D"; return false; }
@@ -249,10 +384,11 @@ bool parse_onnx(const uint8_t *bytes, size_t nbytes, ParsedModel &out, std::stri
                 for (int o = 0; o < out.n_classes; o++) out.fc_b[o] = beta * b->data[o];
             }
             seen_gemm = true;
+            cur = n.out[0];
             i++;
         } else { err = "unsupported ONNX op '" + n.op + "'"; return false; }
     }
-    if (out.convs.empty() || !seen_pool || !seen_gemm) { err = "graph is not Conv/Relu chain + GlobalMaxPool + Gemm"; return false; }
+    if (out.convs.empty() || !seen_pool || !seen_gemm) { err = "graph is not Conv/Relu chain + global max pool + Gemm"; return false; }
     return true;
 }
 

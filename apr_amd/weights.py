@@ -5,7 +5,7 @@ Three on-disk forms are handled here on the host side:
 * the flat ``APRW`` blob (this repo's own trivial format, documented below),
 * a minimal ONNX file writer (used by tests and tools to emit the graph shape
   ``ai/model.py:143-152`` exports; the *reader* is native C++ in
-  ``apr_amd/csrc/onnx_reader.cpp``),
+  ``apr_amd/csrc/model_parse.cpp``),
 * a deterministic random-init generator (own counter-based PRNG, so the 94 MB
   of weights never have to be committed or shipped).
 
@@ -241,8 +241,70 @@ def _value_info(name: str, shape) -> bytes:
     return _s(1, name) + _ld(2, _ld(1, tensor_type))
 
 
-def write_onnx(flat: np.ndarray, n_classes: int, fold_bn: bool = True, raw: bool = True) -> bytes:
-    """Serialise the NoiseDetector graph to ONNX bytes (see module docstring)."""
+def fold_bn_exporter(w, b, g, be, mu, va):
+    """Conv+BatchNorm fold with the arithmetic of the exporter ai/model.py:149-152 calls (the legacy
+    TorchScript exporter's eval-mode peephole): everything in float32, ``scale = g / sqrt(var + eps)``,
+    ``w' = w * scale``, ``b' = (b - mean) * scale + beta``.  Found by bit comparison with a real export
+    (tests/golden/make_onnx_fixture.py): biases and weights agree bit for bit wherever the exporter host's
+    vectorised ``sqrt`` is correctly rounded (it is off by one ulp on a few channels of the wide layers)."""
+    f32 = np.float32
+    w, b, g, be, mu, va = (np.asarray(a, f32) for a in (w, b, g, be, mu, va))
+    scale = g / np.sqrt(va + f32(BN_EPS))
+    return (w * scale[:, None, None, None]).astype(f32), ((b - mu) * scale + be).astype(f32)
+
+
+def write_onnx(flat: np.ndarray, n_classes: int, fold_bn: bool = True, raw: bool = True, style: str = "torch") -> bytes:
+    """Serialise the NoiseDetector graph to ONNX bytes (see module docstring).
+
+    ``style="torch"`` (default) reproduces, field for field, the file the reference's own export call
+    writes (ai/model.py:149-152 with torch 2.10; structure pinned by tests/golden/onnx_real_export.json):
+    ir_version 9, node / value / initialiser names of the TorchScript exporter (``onnx::Conv_127`` ...,
+    ``/features/features.0/Conv`` ...), BatchNorm folded in float32, the pool written as
+    ``MaxPool(kernel_shape [2,3], pads 0, strides [2,3])``, classifier initialisers first, all ``raw_data``.
+    ``fold_bn`` and ``raw`` are ignored in this style (the exporter always folds and always writes raw).
+    ``style="plain"`` is the repo's earlier own form (short names, ``GlobalMaxPool``, optional explicit
+    BatchNormalization nodes, optional packed ``float_data``): kept because the reader accepts those too.
+    """
+    if style == "plain":
+        return _write_onnx_plain(flat, n_classes, fold_bn, raw)
+    if style != "torch":
+        raise ValueError("style must be 'torch' or 'plain'")
+    sd = to_state_dict(flat, n_classes)
+    nodes, conv_inits = [], []
+    cur = "input"
+    h, w_ = 128, 188
+    for l in range(12):
+        ci, bi = 3 * l, 3 * l + 1
+        wf, bf = fold_bn_exporter(sd[f"features.{ci}.weight"], sd[f"features.{ci}.bias"], sd[f"features.{bi}.weight"],
+                                  sd[f"features.{bi}.bias"], sd[f"features.{bi}.running_mean"], sd[f"features.{bi}.running_var"])
+        s = LAYER_STRIDE[l]
+        h, w_ = (h + 2 - 3) // s + 1, (w_ + 2 - 3) // s + 1
+        wn, bn = f"onnx::Conv_{127 + 3 * l}", f"onnx::Conv_{128 + 3 * l}"
+        conv_inits += [_tensor(wn, wf), _tensor(bn, bf)]
+        conv_attrs = [_attr_ints("dilations", [1, 1]), _attr_int("group", 1), _attr_ints("kernel_shape", [3, 3]),
+                      _attr_ints("pads", [1, 1, 1, 1]), _attr_ints("strides", [s, s])]
+        co = f"/features/features.{ci}/Conv_output_0"
+        nodes.append(_node("Conv", [cur, wn, bn], [co], conv_attrs, f"/features/features.{ci}/Conv"))
+        cur = f"/features/features.{ci + 2}/Relu_output_0"
+        nodes.append(_node("Relu", [co], [cur], (), f"/features/features.{ci + 2}/Relu"))
+    # AdaptiveMaxPool2d(1) on a map of known size (2 x 3): MaxPool over the whole map
+    po = "/classifier/classifier.0/MaxPool_output_0"
+    nodes.append(_node("MaxPool", [cur], [po], [_attr_ints("kernel_shape", [h, w_]), _attr_ints("pads", [0, 0, 0, 0]),
+                                                _attr_ints("strides", [h, w_])], "/classifier/classifier.0/MaxPool"))
+    fo = "/classifier/classifier.1/Flatten_output_0"
+    nodes.append(_node("Flatten", [po], [fo], [_attr_int("axis", 1)], "/classifier/classifier.1/Flatten"))
+    nodes.append(_node("Gemm", [fo, "classifier.3.weight", "classifier.3.bias"], ["output"],
+                       [_attr_float("alpha", 1.0), _attr_float("beta", 1.0), _attr_int("transB", 1)], "/classifier/classifier.3/Gemm"))
+    inits = [_tensor("classifier.3.weight", sd["classifier.3.weight"]), _tensor("classifier.3.bias", sd["classifier.3.bias"])] + conv_inits
+    graph = b"".join(_ld(1, n) for n in nodes) + _s(2, "main_graph")
+    graph += b"".join(_ld(5, t) for t in inits)
+    graph += _ld(11, _value_info("input", [1, 1, 128, 188]))
+    graph += _ld(12, _value_info("output", [1, n_classes]))
+    return _vi(1, 9) + _s(2, "pytorch") + _s(3, "2.10.0") + _ld(7, graph) + _ld(8, _vi(2, 20))
+
+
+def _write_onnx_plain(flat: np.ndarray, n_classes: int, fold_bn: bool = True, raw: bool = True) -> bytes:
+    """The repo's own earlier form of the graph (not what the exporter writes; see ``write_onnx``)."""
     sd = to_state_dict(flat, n_classes)
     nodes, inits = [], []
     cur = "input"
@@ -288,3 +350,250 @@ def write_onnx(flat: np.ndarray, n_classes: int, fold_bn: bool = True, raw: bool
     model = _vi(1, 8) + _s(2, "pytorch") + _s(3, "2.10.0") + _ld(7, graph)
     model += _ld(8, _s(1, "") + _vi(2, 20))  # opset_import {domain "", version 20}
     return model
+
+
+# --------------------------------------------------------------------------
+# ONNX structure dump: everything about a file except the weight payloads, as
+# plain JSON-able data.  tests/golden/make_onnx_fixture.py applies it to a real
+# export of the reference's model; the CPU tests apply it to write_onnx()'s
+# output and compare.  Generic protobuf walk + the ONNX field numbers
+# (onnx.proto: ModelProto, GraphProto, NodeProto, AttributeProto, TensorProto,
+# ValueInfoProto).
+# --------------------------------------------------------------------------
+def _rd_varint(b, i):
+    v = 0
+    sh = 0
+    while True:
+        x = b[i]
+        i += 1
+        v |= (x & 0x7F) << sh
+        sh += 7
+        if not x & 0x80:
+            return v, i
+
+
+def _fields(b):
+    """[(field, wire type, value)]: varints as int, length-delimited as memoryview, fixed as bytes."""
+    b = memoryview(b)
+    i, out = 0, []
+    while i < len(b):
+        k, i = _rd_varint(b, i)
+        f, wt = k >> 3, k & 7
+        if wt == 0:
+            v, i = _rd_varint(b, i)
+        elif wt == 2:
+            n, i = _rd_varint(b, i)
+            if i + n > len(b):
+                raise ValueError("truncated protobuf")
+            v = b[i:i + n]
+            i += n
+        elif wt == 5:
+            v = bytes(b[i:i + 4])
+            i += 4
+        elif wt == 1:
+            v = bytes(b[i:i + 8])
+            i += 8
+        else:
+            raise ValueError(f"wire type {wt}")
+        out.append((f, wt, v))
+    return out
+
+
+_ATTR_TYPES = {1: "FLOAT", 2: "INT", 3: "STRING", 4: "TENSOR", 6: "FLOATS", 7: "INTS", 8: "STRINGS"}
+
+
+def _attr_struct(b):
+    name, typ, ints, floats, val = "", 0, [], [], None
+    order = []
+    for f, wt, v in _fields(b):
+        order.append(f)
+        if f == 1:
+            name = bytes(v).decode()
+        elif f == 2:
+            val = struct.unpack("<f", v)[0]
+        elif f == 3:
+            val = v
+        elif f == 4:
+            val = bytes(v).decode()
+        elif f == 7 and wt == 5:
+            floats.append(struct.unpack("<f", v)[0])
+        elif f == 8 and wt == 0:
+            ints.append(v)
+        elif f == 8 and wt == 2:
+            j, mv = 0, v
+            while j < len(mv):
+                x, j = _rd_varint(mv, j)
+                ints.append(x)
+        elif f == 20:
+            typ = v
+    if typ == 7:
+        val = ints
+    elif typ == 6:
+        val = floats
+    return {"name": name, "type": _ATTR_TYPES.get(typ, typ), "value": val, "field_order": order}
+
+
+def _value_info_struct(b):
+    name, elem, dims = "", None, []
+    for f, wt, v in _fields(b):
+        if f == 1:
+            name = bytes(v).decode()
+        elif f == 2:
+            for f2, _, v2 in _fields(v):
+                if f2 == 1:
+                    for f3, _, v3 in _fields(v2):
+                        if f3 == 1:
+                            elem = v3
+                        elif f3 == 2:
+                            for f4, _, v4 in _fields(v3):
+                                if f4 == 1:
+                                    d = None
+                                    for f5, wt5, v5 in _fields(v4):
+                                        d = v5 if wt5 == 0 else bytes(v5).decode()
+                                    dims.append(d)
+    return {"name": name, "elem_type": elem, "shape": dims}
+
+
+def onnx_structure(data: bytes) -> dict:
+    """Everything in an ONNX file but the weight values: model fields, node list (op, name, inputs, outputs,
+    attributes with types and values, in file order), initialisers (name, dims, data type, which storage field,
+    byte count, sha256 of the payload), graph inputs / outputs, the order of the fields as serialised, and
+    ``skeleton_sha256`` = sha256 of the file with every initialiser payload cut out (its length prefix kept):
+    two files with equal skeletons differ in weight bytes only."""
+    import hashlib
+    data = bytes(data)
+    out = {"file_bytes": len(data), "model_field_order": [], "opset_import": [], "graph": None}
+    skel = hashlib.sha256()
+    mv = memoryview(data)
+    holes = []                                    # (start, end) of initialiser payloads, absolute offsets
+
+    # a walk that keeps absolute offsets, for the three levels that lead to a payload
+    def walk(b, base):
+        i, res = 0, []
+        while i < len(b):
+            k, i = _rd_varint(b, i)
+            f, wt = k >> 3, k & 7
+            if wt == 0:
+                v, i = _rd_varint(b, i)
+                res.append((f, wt, v, None))
+            elif wt == 2:
+                n, i = _rd_varint(b, i)
+                if i + n > len(b):
+                    raise ValueError("truncated protobuf")
+                res.append((f, wt, b[i:i + n], base + i))
+                i += n
+            elif wt == 5:
+                res.append((f, wt, bytes(b[i:i + 4]), None))
+                i += 4
+            elif wt == 1:
+                res.append((f, wt, bytes(b[i:i + 8]), None))
+                i += 8
+            else:
+                raise ValueError(f"wire type {wt}")
+        return res
+
+    for f, wt, v, off in walk(mv, 0):
+        out["model_field_order"].append(f)
+        if f == 1:
+            out["ir_version"] = v
+        elif f == 2:
+            out["producer_name"] = bytes(v).decode()
+        elif f == 3:
+            out["producer_version"] = bytes(v).decode()
+        elif f == 4:
+            out["domain"] = bytes(v).decode()
+        elif f == 5:
+            out["model_version"] = v
+        elif f == 6:
+            out["doc_string"] = bytes(v).decode()
+        elif f == 8:
+            o = {"domain": None, "version": None}
+            for f2, _, v2 in _fields(v):
+                if f2 == 1:
+                    o["domain"] = bytes(v2).decode()
+                elif f2 == 2:
+                    o["version"] = v2
+            out["opset_import"].append(o)
+        elif f == 7:
+            g = {"name": None, "field_order": [], "nodes": [], "initializers": [], "inputs": [], "outputs": [], "value_info": []}
+            for gf, gwt, gv, goff in walk(v, off):
+                if not g["field_order"] or g["field_order"][-1][0] != gf:
+                    g["field_order"].append([gf, 1])
+                else:
+                    g["field_order"][-1][1] += 1
+                if gf == 1:
+                    n = {"op": None, "name": "", "domain": "", "inputs": [], "outputs": [], "attrs": [], "field_order": []}
+                    for nf, _, nv in _fields(gv):
+                        n["field_order"].append(nf)
+                        if nf == 1:
+                            n["inputs"].append(bytes(nv).decode())
+                        elif nf == 2:
+                            n["outputs"].append(bytes(nv).decode())
+                        elif nf == 3:
+                            n["name"] = bytes(nv).decode()
+                        elif nf == 4:
+                            n["op"] = bytes(nv).decode()
+                        elif nf == 5:
+                            n["attrs"].append(_attr_struct(nv))
+                        elif nf == 7:
+                            n["domain"] = bytes(nv).decode()
+                    g["nodes"].append(n)
+                elif gf == 2:
+                    g["name"] = bytes(gv).decode()
+                elif gf == 5:
+                    t = {"name": "", "dims": [], "data_type": None, "storage": None, "nbytes": 0, "sha256": None, "field_order": []}
+                    for tf, twt, tv, toff in walk(gv, goff):
+                        t["field_order"].append(tf)
+                        if tf == 1 and twt == 0:
+                            t["dims"].append(tv)
+                        elif tf == 2:
+                            t["data_type"] = tv
+                        elif tf == 8:
+                            t["name"] = bytes(tv).decode()
+                        elif tf in (4, 9) and twt == 2:
+                            t["storage"] = "raw_data" if tf == 9 else "float_data"
+                            t["nbytes"] = len(tv)
+                            t["sha256"] = hashlib.sha256(tv).hexdigest()
+                            holes.append((toff, toff + len(tv)))
+                        elif tf == 4 and twt == 5:
+                            t["storage"] = "float_data (unpacked)"
+                    t["field_order"] = sorted(set(t["field_order"]), key=t["field_order"].index)
+                    g["initializers"].append(t)
+                elif gf == 11:
+                    g["inputs"].append(_value_info_struct(gv))
+                elif gf == 12:
+                    g["outputs"].append(_value_info_struct(gv))
+                elif gf == 13:
+                    g["value_info"].append(_value_info_struct(gv))
+            out["graph"] = g
+    pos = 0
+    for a, b in sorted(holes):
+        skel.update(mv[pos:a])
+        pos = b
+    skel.update(mv[pos:])
+    out["skeleton_sha256"] = skel.hexdigest()
+    return out
+
+
+def onnx_initializers(data: bytes) -> dict:
+    """{name: float32 ndarray} of the FLOAT initialisers stored as raw_data or packed float_data."""
+    res = {}
+    for f, _, v in _fields(data):
+        if f != 7:
+            continue
+        for gf, _, gv in _fields(v):
+            if gf != 5:
+                continue
+            dims, name, arr, dt = [], "", None, None
+            for tf, twt, tv in _fields(gv):
+                if tf == 1 and twt == 0:
+                    dims.append(tv)
+                elif tf == 2:
+                    dt = tv
+                elif tf == 8:
+                    name = bytes(tv).decode()
+                elif tf in (4, 9) and twt == 2:
+                    arr = np.frombuffer(tv, "<f4")
+            if dt == 1 and arr is not None:
+                res[name] = arr.reshape(dims)
+    return res

@@ -63,9 +63,15 @@ const char *apr_version(void);
  * Create an engine on GPU `device_id`.
  *   model_bytes/n : the bytes model.Load keeps in OnnxModel.RawBytes
  *                   (src/model/model.go:54-83): an ONNX file as exported by
- *                   ai/model.py:143-152 (Conv[+BatchNormalization]+Relu x12,
- *                   GlobalMaxPool, Flatten, Gemm), or this repo's flat "APRW"
- *                   blob (apr_amd/weights.py).  NULL/0 creates a
+ *                   ai/model.py:143-152 -- [Conv(+folded BatchNorm) -> Relu] x12,
+ *                   MaxPool(kernel_shape [2,3] = the last conv's whole output map,
+ *                   pads 0), Flatten, Gemm(transB 1); structure of a real export:
+ *                   tests/golden/onnx_real_export.json -- or this repo's flat "APRW"
+ *                   blob (apr_amd/weights.py).  Also accepted: explicit
+ *                   BatchNormalization nodes and GlobalMaxPool as the pool.  A
+ *                   MaxPool that is not the whole map, a graph input that is not
+ *                   [N,1,128,188], or a node list that is not one chain is
+ *                   APR_ERR_MODEL with the reason.  NULL/0 creates a
  *                   front-end-only engine (enough for Prepare).
  *   max_batch     : windows processed per GPU pass (activation buffers are
  *                   sized for it); <=0 picks the default (1024).  max_batch <= 4

@@ -115,11 +115,22 @@ def test_infer_torch_default_init_golden():
     assert np.abs(got - want).max() <= 1e-6     # activations shrink ~1e-5 under torch's default init
 
 
+def test_onnx_in_the_real_exporters_form_matches_reference_logits(he_weights):
+    # the file ai/model.py:149-152 writes (structure pinned to a real export by tests/golden/onnx_real_export.json and
+    # tests/test_host.py: MaxPool[2,3], f32-folded BatchNorm, onnx::Conv_N names) against logits from the reference's own class
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
+    e = model.Engine(W.write_onnx(he_weights, 4, style="torch"), 0, 8)
+    got = e.infer_logits(specs)
+    e.close()
+    assert np.abs(got - want).max() <= LOGIT_TOL
+
+
 def test_onnx_folded_and_unfolded_equal_blob(eng, he_weights):
     specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))[:3]
     base = eng.infer_logits(specs)
     for fold, raw in ((True, True), (False, True), (False, False)):
-        e = model.Engine(W.write_onnx(he_weights, 4, fold_bn=fold, raw=raw), 0, 8)
+        e = model.Engine(W.write_onnx(he_weights, 4, fold_bn=fold, raw=raw, style="plain"), 0, 8)
         got = e.infer_logits(specs)
         e.close()
         assert np.abs(got - base).max() <= 2e-5, (fold, raw)

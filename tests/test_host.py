@@ -40,8 +40,9 @@ def test_blob_and_onnx_parse(he_weights):
     flat, nc = W.unpack_blob(blob)
     assert nc == 4 and np.array_equal(flat, he_weights)
     assert model.model_info(blob) == (4, 12)
+    assert model.model_info(W.write_onnx(he_weights, 4)) == (4, 12)                 # the real exporter's form (default)
     for fold, raw in ((True, True), (False, True), (False, False)):
-        assert model.model_info(W.write_onnx(he_weights, 4, fold, raw)) == (4, 12)
+        assert model.model_info(W.write_onnx(he_weights, 4, fold, raw, style="plain")) == (4, 12)
     sd = W.to_state_dict(he_weights, 4)
     assert len(sd) == 12 * 6 + 2 and np.array_equal(W.from_state_dict(sd, 4), he_weights)
 
@@ -197,20 +198,123 @@ def test_resample_taps_match_oracle_definition():
             sweep.resample_taps(*bad)
 
 
-def _tiny_onnx(gemm_dims, gemm_floats, trans_b=1, conv_dims=(32, 1, 3, 3)):
-    """Conv -> Relu -> GlobalMaxPool -> Flatten -> Gemm with hand-set (possibly lying) dims."""
+def _tiny_onnx(gemm_dims, gemm_floats, trans_b=1, conv_dims=(32, 1, 3, 3), pool=None, stride=1, input_shape=None,
+               relu_in="c", flatten_in="p"):
+    """Conv -> Relu -> pool -> Flatten -> Gemm with hand-set (possibly lying) dims.  ``pool`` = None: GlobalMaxPool;
+    else the attribute list of a MaxPool node."""
     def tensor(name, dims, n_floats):
         t = b"".join(W._vi(1, d) for d in dims) + W._vi(2, 1)
         return t + W._s(8, name) + W._ld(9, np.zeros(n_floats, "<f4").tobytes())
-    conv_attrs = [W._attr_ints("pads", [1, 1, 1, 1]), W._attr_ints("strides", [1, 1])]
-    nodes = [W._node("Conv", ["input", "w", "b"], ["c"], conv_attrs), W._node("Relu", ["c"], ["r"]),
-             W._node("GlobalMaxPool", ["r"], ["p"]), W._node("Flatten", ["p"], ["f"]),
+    conv_attrs = [W._attr_ints("pads", [1, 1, 1, 1]), W._attr_ints("strides", [stride, stride])]
+    pool_node = W._node("GlobalMaxPool", ["r"], ["p"]) if pool is None else W._node("MaxPool", ["r"], ["p"], pool)
+    nodes = [W._node("Conv", ["input", "w", "b"], ["c"], conv_attrs), W._node("Relu", [relu_in], ["r"]),
+             pool_node, W._node("Flatten", [flatten_in], ["f"]),
              W._node("Gemm", ["f", "fw"], ["output"], [W._attr_int("transB", trans_b)])]
     n_conv = int(np.prod([max(d, 0) for d in conv_dims]))
     inits = [tensor("w", conv_dims, min(n_conv, 1 << 16)), tensor("b", [max(conv_dims[0], 0)], min(max(conv_dims[0], 0), 64)),
              tensor("fw", gemm_dims, gemm_floats)]
     graph = b"".join(W._ld(1, n) for n in nodes) + b"".join(W._ld(5, t) for t in inits)
+    if input_shape is not None:
+        graph += W._ld(11, W._value_info("input", input_shape))
     return W._vi(1, 8) + W._ld(7, graph)
+
+
+def _fixture():
+    import json
+    with open(os.path.join(REPO, "tests", "golden", "onnx_real_export.json")) as f:
+        return json.load(f)
+
+
+def _bare(st):
+    """A structure dump without what depends on the weight values or on how the fixture was made."""
+    import json
+    st = json.loads(json.dumps(st))
+    for k in ("how", "writer_vs_real_on_this_host", "apr_model_info"):
+        st.pop(k, None)
+    for t in st["graph"]["initializers"]:
+        t.pop("sha256")
+    return st
+
+
+def test_writer_reproduces_the_real_exporters_file_structure(he_weights):
+    # tests/golden/onnx_real_export.json = the structure of the file the reference's own export call writes for the reference's
+    # own NoiseDetector (made by tests/golden/make_onnx_fixture.py in the build container).  The writer's default style must
+    # be that file but for the weight values: same fields in the same order, names, attributes, dims, storage -- byte for byte
+    # (skeleton_sha256 hashes the whole serialisation with the payloads cut out).
+    fx = _fixture()
+    g = fx["graph"]
+    ops = [n["op"] for n in g["nodes"]]
+    assert ops == ["Conv", "Relu"] * 12 + ["MaxPool", "Flatten", "Gemm"]            # NOT GlobalMaxPool (SURVEY.md:355 guessed wrong)
+    pool = {a["name"]: a["value"] for a in g["nodes"][24]["attrs"]}
+    assert pool == {"kernel_shape": [2, 3], "pads": [0, 0, 0, 0], "strides": [2, 3]}
+    assert fx["ir_version"] == 9 and fx["opset_import"] == [{"domain": None, "version": 20}] and fx["apr_model_info"] == [4, 12]
+    assert all(t["storage"] == "raw_data" and t["data_type"] == 1 for t in g["initializers"])
+    assert [t["name"] for t in g["initializers"][:4]] == ["classifier.3.weight", "classifier.3.bias", "onnx::Conv_127", "onnx::Conv_128"]
+    mine = W.write_onnx(he_weights, 4)
+    st = W.onnx_structure(mine)
+    assert _bare(st) == _bare(fx)
+    assert st["skeleton_sha256"] == fx["skeleton_sha256"] and st["file_bytes"] == fx["file_bytes"] == len(mine)
+    # weight values: the fixture was exported with these same he-seed-0 weights.  Payloads the exporter host computed with
+    # correctly rounded arithmetic are bit-identical (sha256); the others differ by one ulp of the BatchNorm scale on a few channels
+    # (that host's vectorised sqrt), so every payload's first floats agree to 1e-6 relative.
+    vs = fx["writer_vs_real_on_this_host"]
+    arrays = W.onnx_initializers(mine)
+    same = 0
+    for t_fx, t in zip(g["initializers"], st["graph"]["initializers"]):
+        v = vs[t["name"]]
+        if v["bit_mismatches"] == 0:
+            assert t["sha256"] == t_fx["sha256"], t["name"]
+            same += 1
+        assert v["max_rel_diff_of_l2"] <= 1e-7
+        np.testing.assert_allclose(arrays[t["name"]].reshape(-1)[:4], v["head"], rtol=1e-6, atol=0)
+    assert same >= 8      # classifier weight + bias, layer 1, several biases
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ai"), reason="build container only: needs the reference to export from")
+def test_real_export_of_the_reference_model_loads(he_weights):
+    # the real thing, end to end on the host: ai/model.py:149-152's export of ai/model.py's NoiseDetector -> apr_model_info
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    import make_onnx_fixture as mk
+    data, flat = mk.export_reference()
+    assert np.array_equal(flat, he_weights)
+    assert model.model_info(data) == (4, 12)
+    fx = _fixture()
+    assert hashlib.sha256(data).hexdigest() == fx["how"]["file_sha256"]              # the fixture describes this very file
+    real, mine = W.onnx_initializers(data), W.onnx_initializers(W.write_onnx(he_weights, 4))
+    assert list(real) == list(mine)
+    for name, a in real.items():
+        assert a.shape == mine[name].shape
+        # 1e-6 relative; a bias that is a near-cancellation of its terms is measured against the tensor's own scale
+        np.testing.assert_allclose(mine[name], a, rtol=1e-6, atol=1e-6 * float(np.abs(a).max()), err_msg=name)
+
+
+def test_maxpool_is_accepted_only_as_the_global_pool():
+    # one stride-1 conv at 128x188 -> the whole map is [128,188]; one stride-2 conv -> [64,94]
+    ks = lambda v: W._attr_ints("kernel_shape", v)
+    ok = [ks([128, 188]), W._attr_ints("pads", [0, 0, 0, 0]), W._attr_ints("strides", [128, 188])]
+    assert model.model_info(_tiny_onnx([4, 32], 128, pool=ok)) == (4, 1)
+    assert model.model_info(_tiny_onnx([4, 32], 128, pool=[ks([128, 188])])) == (4, 1)                 # pads / strides defaulted
+    assert model.model_info(_tiny_onnx([4, 32], 128, pool=[ks([64, 94])], stride=2)) == (4, 1)
+    assert model.model_info(_tiny_onnx([4, 32], 128, pool=ok, input_shape=[1, 1, 128, 188])) == (4, 1)
+    for pool, kw, why in (([ks([2, 3])], {}, "whole [128,188] output map"), ([ks([128, 188])], {"stride": 2}, "whole [64,94] output map"),
+                          ([], {}, "kernel_shape none"), ([ks([128, 188]), W._attr_ints("pads", [0, 1, 0, 0])], {}, "padding"),
+                          ([ks([128, 188]), W._attr_ints("dilations", [2, 1])], {}, "dilated"),
+                          ([ks([128])], {}, "whole [128,188] output map"),
+                          (ok, {"input_shape": [1, 1, 64, 188]}, "128x188 spectrograms only"),
+                          (ok, {"input_shape": [1, 3, 128, 188]}, "128x188 spectrograms only")):
+        with pytest.raises(_capi.AprError) as ei:
+            model.model_info(_tiny_onnx([4, 32], 128, pool=pool, **kw))
+        assert ei.value.code == _capi.ERR_MODEL and why in str(ei.value), (why, str(ei.value))
+
+
+def test_graph_must_be_one_chain():
+    assert model.model_info(_tiny_onnx([4, 32], 128)) == (4, 1)
+    for kw in ({"relu_in": "input"}, {"flatten_in": "r"}):
+        with pytest.raises(_capi.AprError) as ei:
+            model.model_info(_tiny_onnx([4, 32], 128, **kw))
+        assert ei.value.code == _capi.ERR_MODEL and "not one chain" in str(ei.value)
 
 
 def test_gemm_and_conv_dims_are_checked_against_payload():
