@@ -167,6 +167,52 @@ def plan_shards(n_files: int, seconds: int, world: int, rank: int) -> ShardPlan:
 
 
 # ----------------------------------------------------------------------------------------------
+# BASELINE config 5: the training set's tagged clips preprocessed by `world` ranks
+# (ai/train.py:36-52 extracts one clip's features per __getitem__; SURVEY 8(e): "Cfg 5: by clip index")
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class ClipPlan:
+    lo: int                     # this rank's clips are [lo, hi) of the data set's index order
+    hi: int
+    counts: List[int]           # clips of every rank
+
+    @property
+    def n_local(self) -> int:
+        return self.hi - self.lo
+
+
+def plan_clips(n_clips: int, world: int, rank: int) -> ClipPlan:
+    """Contiguous blocks by clip index: rank r holds rows [r*n//world, (r+1)*n//world) of the [n,1,128,188] feature
+    tensor, so the shards concatenated in rank order ARE the data set's order (10 000 clips over 8 ranks: 1 250 each).
+    Clips are independent and of one size (192 000 bytes, src/review/action.go:212-215): no exchange is needed."""
+    if n_clips < 0 or world < 1 or not 0 <= rank < world:
+        raise ValueError("plan_clips: bad arguments")
+    edges = [r * n_clips // world for r in range(world + 1)]
+    return ClipPlan(edges[rank], edges[rank + 1], [edges[r + 1] - edges[r] for r in range(world)])
+
+
+def gather_features(feat, counts: Sequence[int], dist=None, dst: int = 0):
+    """Optional: the per-rank feature rows [n_local,128,188] f32 gathered on ``dst`` (padded to max(counts); 962 MB for
+    config 5, which is why bench.py leaves it off by default: a trainer reads each shard on the GPU that made it).
+    Returns the [sum(counts),128,188] tensor on dst, None elsewhere."""
+    import torch
+    if dist is None:
+        import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return feat
+    if len(counts) != world or feat.shape[0] != counts[rank]:
+        raise ValueError("gather_features: counts must list every rank's clips")
+    cap = int(max(counts))
+    pad = feat if feat.shape[0] == cap else torch.cat([feat, feat.new_zeros((cap - feat.shape[0],) + tuple(feat.shape[1:]))])
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([bufs[r][: counts[r]] for r in range(world)])
+
+
+# ----------------------------------------------------------------------------------------------
 # tagged clips on disk: tags/<tag>/<file>:<n>.dat = 2 s of raw s16le 48 kHz
 # (src/review/action.go:190-224 writes them, ai/model.py:155-160 / ai/train.py:128-135 read them)
 # ----------------------------------------------------------------------------------------------

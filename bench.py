@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- audio-hours scored per second on N MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path (PCM -> STFT -> log-mel -> CNN -> softmax -> label) over
@@ -14,6 +14,11 @@ record_duration, src/state/config.go:83); fp32 end to end; random-init NoiseDete
   --config 3            BASELINE config 3, --hours H (default 1000) = 6 H recordings in ALL,
                         sharded by file, round-robin, over the N ranks ("scaling": "strong");
                         each rank synthesises its shard in chunks straight into HBM.
+
+  --config 5            BASELINE config 5, training-set preprocessing (ai/train.py:36-52): --clips (default 10 000)
+                        tagged 192 000-byte clips -> [n,1,128,188] f32 log-mel in the librosa flavour, clips sharded
+                        by index over the N ranks (contiguous blocks, 1 250 each at 8), every rank's features stay
+                        on its GPU (--gather collects them on rank 0: 962 MB); the line reports clips/s.
 
 N > 1: one process per GPU.  Started by torchrun, the ranks come from the environment; started
 as plain `python bench.py --gpus N`, this process only spawns N fresh rank processes (it never
@@ -52,7 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5))
+    ap.add_argument("--clips", type=int, default=10000, help="config 5: clips in the whole job")
+    ap.add_argument("--gather", action="store_true", help="config 5: gather the feature rows on rank 0 inside every step")
     ap.add_argument("--files", type=int, default=60, help="config 2: recordings per GPU")
     ap.add_argument("--hours", type=float, default=1000.0, help="config 3: hours of audio in the whole job")
     ap.add_argument("--seconds", type=int, default=600, help="seconds per recording")
@@ -172,6 +179,9 @@ def main() -> int:
         if dist.get_world_size() != args.gpus:      # the world RCCL actually built
             sys.stderr.write(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}\n")
             return 2
+
+    if args.config == 5:
+        return run_config5(args, rank, local_rank, world, dev, dry, torch, dist)
 
     # ---- the job's recordings and this rank's shard (by file, round-robin: SURVEY 8(e)) ----
     n_files_total = args.files * world if args.config == 2 else max(world, int(round(args.hours * 3600 / args.seconds)))
@@ -526,25 +536,159 @@ def leg_live_streams(model, blob, device, empty, streams=256, ticks=24):
             "note": "apr_stream_tick, segment arrival in host memory to labels in host memory"}
 
 
+CLIP_BYTES = 192000            # a tagged .dat clip: two 1-s segments (src/review/action.go:212-215)
+CLIP_UNIQUE = 500              # distinct synthetic clips; clip i of the data set is synthetic clip i % 500
+CLIP_ALG_BYTES = CLIP_BYTES + 128 * 188 * 4     # algorithmic bytes per clip: PCM in + [128,188] f32 out
+
+
+def config5_clips(model, torch, dev, lo, hi):
+    """Clips [lo, hi) of the synthetic data set, packed at stride 192000, resident in HBM."""
+    host = np.concatenate([model.synth_pcm(5, i, 2) for i in range(CLIP_UNIQUE)]).view(np.uint8).reshape(CLIP_UNIQUE, CLIP_BYTES)
+    idx = np.arange(lo, hi) % CLIP_UNIQUE
+    return torch.from_numpy(np.ascontiguousarray(host[idx]).reshape(-1)).to(dev)
+
+
 def leg_training_features(model, torch, dev, device, clips=10000):
     """BASELINE config 5: 10 000 tagged .dat clips -> librosa-flavour log-mel (ai/train.py:36-52), clips resident in HBM."""
     from apr_amd._capi import FLAVOUR_LIBROSA
     fe = model.Engine(None, device, 1024)
-    uniq = 500
-    host = np.concatenate([model.synth_pcm(5, i, 2) for i in range(uniq)]).view(np.uint8)
-    d_pcm = torch.from_numpy(np.tile(host, (clips + uniq - 1) // uniq)[: clips * 192000]).to(dev)
+    d_pcm = config5_clips(model, torch, dev, 0, clips)
     d_out = torch.empty((clips, 128, 188), dtype=torch.float32, device=dev)
-    fe.prepare_batch_device(d_pcm, d_pcm.numel(), clips, 192000, d_out, FLAVOUR_LIBROSA)
+    fe.prepare_batch_device(d_pcm, d_pcm.numel(), clips, CLIP_BYTES, d_out, FLAVOUR_LIBROSA)
     fe.sync()
     t1 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        fe.prepare_batch_device(d_pcm, d_pcm.numel(), clips, 192000, d_out, FLAVOUR_LIBROSA)
+        fe.prepare_batch_device(d_pcm, d_pcm.numel(), clips, CLIP_BYTES, d_out, FLAVOUR_LIBROSA)
     fe.sync()
     dt = (time.perf_counter() - t1) / reps
     fe.close()
     return {"workload": f"BASELINE config 5: {clips} x 192000-byte clips -> [n,1,128,188] f32, librosa flavour, one GPU",
-            "ms": 1e3 * dt, "clips_per_s": clips / dt, "algorithmic_GBps": clips * (192000 + 128 * 188 * 4) / dt / 1e9}
+            "ms": 1e3 * dt, "clips_per_s": clips / dt, "algorithmic_GBps": clips * CLIP_ALG_BYTES / dt / 1e9}
+
+
+def fake_features(lo, hi):
+    """dry run: a recomputable stand-in for the feature rows of clips [lo, hi) (small rows: the plan and the gather are under test)"""
+    i = np.arange(lo, hi, dtype=np.float32)[:, None, None]
+    return (i + np.arange(2, dtype=np.float32)[None, :, None] * 0.25 + np.arange(3, dtype=np.float32)[None, None, :] * 0.5)
+
+
+def run_config5(args, rank, local_rank, world, dev, dry, torch, dist) -> int:
+    """BASELINE config 5 over the ranks: one step = every rank's clips through the librosa-flavour front end."""
+    from apr_amd import sweep
+    cp = sweep.plan_clips(args.clips, world, rank)
+    n = cp.n_local
+    fe = None
+    if dry:
+        d_out = torch.from_numpy(fake_features(cp.lo, cp.hi))
+    else:
+        from apr_amd import model
+        from apr_amd._capi import FLAVOUR_LIBROSA
+        fe = model.Engine(None, local_rank, 1024)
+        d_pcm = config5_clips(model, torch, dev, cp.lo, cp.hi)
+        d_out = torch.empty((n, 128, 188), dtype=torch.float32, device=dev)
+    gathered = [None]
+
+    def step():
+        if fe is not None:
+            fe.prepare_batch_device(d_pcm, d_pcm.numel(), n, CLIP_BYTES, d_out, FLAVOUR_LIBROSA)
+        if world > 1 and args.gather:
+            if fe is not None:
+                fe.sync()
+            gathered[0] = sweep.gather_features(d_out, cp.counts, dist)
+
+    def fence():
+        if fe is not None:
+            fe.sync()
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        if fe is not None:
+            torch.cuda.synchronize()
+
+    if world > 1 and not dry:
+        dist.all_reduce(torch.zeros(1, device=dev))          # RCCL builds its rings on the first collective
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if fe is not None and not args.no_profile:
+        fe.profile_reset()
+        fe.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = None
+    if fe is not None and not args.no_profile:
+        prof = fe.profile_read()
+        fe.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    clips_per_s = args.clips * args.steps / dt
+    out = {"metric": "training clips preprocessed/sec per node (BASELINE config 5)", "value": None if dry else clips_per_s, "unit": "clips/s",
+           "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"BASELINE config 5: {args.clips} x {CLIP_BYTES}-byte tagged clips -> [n,1,128,188] f32 log-mel, librosa flavour "
+                                  f"(ai/train.py:36-52), sharded by clip index over {world} GPU(s)",
+                      "baseline_config": 5, "clips_total": args.clips, "clips_per_rank": [int(c) for c in cp.counts],
+                      "sharding": "by clip index, contiguous blocks; features stay on the GPU that made them"
+                                  + ("; gathered on rank 0 each step" if args.gather and world > 1 else "")},
+           "audio_hours_per_s": None if dry else clips_per_s * 2.0 / 3600.0}
+    if dry:
+        out["dry_run"] = True
+    ok = True
+    if world > 1 and args.gather:
+        g = gathered[0]
+        ok = g is not None and g.shape[0] == args.clips
+        if dry:
+            ok = ok and np.array_equal(g.numpy(), fake_features(0, args.clips))
+        else:
+            ok = ok and bool(torch.equal(g[: cp.counts[0]], d_out)) and bool(((g >= 0) & (g <= 1)).all())
+        out["gather"] = {"rows": [int(c) for c in cp.counts], "bytes_per_step": int(args.clips) * int(np.prod(d_out.shape[1:])) * 4, "verified": bool(ok)}
+    if prof:
+        fam = {}
+        for s in prof:
+            a = fam.setdefault(s["name"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            for k in ("ms", "launches", "flops", "bytes"):
+                a[k] += s[k]
+        tot_ms = sum(a["ms"] for a in fam.values())
+        dom_name, dom = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        # SURVEY 8(d) prices the front end against HBM; DESIGN.md section 4 shows the kernel is VALU/LDS-bound (its HBM floor is far below)
+        out["roofline"] = {"kernel": dom_name, "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                           "traffic": None, "algorithmic_bytes_per_launch": dom["bytes"] / max(dom["launches"], 1),
+                           "avg_launch_ms": dom["ms"] / max(dom["launches"], 1), "launches": dom["launches"], "share_of_gpu_time": dom["ms"] / tot_ms,
+                           "valu_tflops": dom["flops"] / (dom["ms"] * 1e-3) / 1e12, "valu_frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_F32_VALU_TFLOPS}
+        out["kernels"] = [{"name": k, "ms_per_step": v["ms"] / args.steps, "launches": v["launches"],
+                           "alg_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else None,
+                           "hbm_frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS if v["ms"] > 0 else None,
+                           "share_of_gpu_time": v["ms"] / tot_ms} for k, v in fam.items()]
+        out["whole_path_alg_GBps"] = args.clips * args.steps * CLIP_ALG_BYTES / dt / 1e9
+    if not dry and world == 1 and args.cpu_windows > 0 and not args.no_extras:
+        import oracle   # test infrastructure; here only the timed CPU stand-in / checker
+        nc = min(256, n)
+        host = d_pcm[: nc * CLIP_BYTES].cpu().numpy()
+        t1 = time.perf_counter()
+        ref = oracle.prepare_librosa_batch(host, nc)
+        cdt = time.perf_counter() - t1
+        got = d_out[:nc].cpu().numpy()
+        out["cpu_baseline"] = {"value": nc / cdt, "unit": "clips/s", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": f"first {nc} clips through the oracle's librosa-flavour restatement (librosa itself is absent: parity unpinned)"}
+        out["parity_sample"] = {"clips": nc, "max_abs_err": float(np.abs(got - ref).max()), "tolerance": 5e-5}
+    if fe is not None:
+        fe.close()
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 3
 
 
 if __name__ == "__main__":

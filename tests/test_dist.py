@@ -135,3 +135,29 @@ def test_bench_launches_its_own_ranks_dry_run():
 def test_bench_refuses_a_world_that_is_not_gpus():
     rc, out, err = _bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "3", "RANK": "0"})
     assert rc != 0 and out is None and "WORLD_SIZE=3 but --gpus 2" in err
+
+
+def test_plan_clips_contiguous_blocks_by_index():
+    # "Cfg 5: by clip index"; 8(d): 10 000 clips, 1 250 per GPU at 8
+    for world in (1, 2, 4, 8):
+        plans = [sweep.plan_clips(10000, world, r) for r in range(world)]
+        assert [p.n_local for p in plans] == [10000 // world] * world == plans[0].counts
+        assert plans[0].lo == 0 and plans[-1].hi == 10000 and all(a.hi == b.lo for a, b in zip(plans, plans[1:]))
+    plans = [sweep.plan_clips(10, 4, r) for r in range(4)]                      # ragged: every clip exactly once, sizes differ by <= 1
+    assert [(p.lo, p.hi) for p in plans] == [(0, 2), (2, 5), (5, 7), (7, 10)] and plans[2].counts == [2, 3, 2, 3]
+    assert sweep.plan_clips(0, 3, 1).n_local == 0 and sweep.plan_clips(2, 8, 7).counts == [0, 0, 0, 1, 0, 0, 0, 1]
+    import pytest
+    with pytest.raises(ValueError):
+        sweep.plan_clips(10, 2, 2)
+
+
+def test_bench_config5_dry_run_shards_by_clip_index():
+    for world in (1, 2, 4, 8):
+        rc, out, err = _bench("--gpus", str(world), "--dry-run", "--config", "5", "--steps", "1", "--warmup", "0")
+        assert rc == 0, err
+        assert out["n_gpus"] == world and out["dry_run"] is True and out["value"] is None and out["unit"] == "clips/s"
+        assert out["config"]["baseline_config"] == 5 and out["config"]["clips_per_rank"] == [10000 // world] * world
+    # with the optional gather: rank 0 ends up with every clip's row, in data-set order
+    rc, out, err = _bench("--gpus", "2", "--dry-run", "--config", "5", "--clips", "11", "--gather", "--steps", "2", "--warmup", "1")
+    assert rc == 0, err
+    assert out["config"]["clips_per_rank"] == [5, 6] and out["gather"] == {"rows": [5, 6], "bytes_per_step": 11 * 6 * 4, "verified": True}
