@@ -42,6 +42,15 @@ class AprError(RuntimeError):
 _lib = None
 
 
+def hip_runtime_mapped():
+    """Paths of the libamdhip64 images mapped into this process (diagnostic: which HIP runtime serves libapr_amd.so)."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+    except OSError:
+        return []
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -53,12 +62,14 @@ def lib():
     # PyTorch ships a HIP runtime of its own, and the runtime that is mapped first serves the whole process: with
     # libapr_amd.so (linked against /opt/rocm) mapped first, a later `import torch` finds no GPU.  Callers that hand
     # torch device tensors to the device-pointer entry points need one shared runtime, so map torch's first when
-    # torch is installed.  Nothing of torch is used here.
+    # torch is installed.  Nothing of torch is used here, and a torch that is absent OR broken (its import can raise
+    # OSError / RuntimeError, not only ImportError) must not make the library unloadable.  APR_PRELOAD_TORCH=0 skips
+    # the preload (host-only tools: apr_model_info, apr_sweep_plan ...).  Version coupling: see INTEGRATION.md.
     import sys
-    if "torch" not in sys.modules:
+    if "torch" not in sys.modules and os.environ.get("APR_PRELOAD_TORCH", "1") != "0":
         try:
             import torch  # noqa: F401
-        except ImportError:
+        except Exception:   # noqa: BLE001
             pass
     L = C.CDLL(LIB_PATH)
     vp, u8p, f32p, f64p = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses (host or device)

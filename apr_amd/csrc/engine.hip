@@ -342,6 +342,16 @@ void add_slot(apr_engine *e, const char *name, int layer)
     s.layer = layer;
 }
 
+// Every kernel-selection switch below is a DEVELOPER knob (A/B timing, the tests that compare kernel forms).  A release
+// process ignores them all unless APR_DEV_KNOBS=1 is set beside them, so that a stray APR_WINOGRAD=0 inherited by a
+// deployment daemon cannot silently cost a quarter of the throughput.
+const char *dev_getenv(const char *name)
+{
+    const char *on = getenv("APR_DEV_KNOBS");
+    if (!on || on[0] != '1') return nullptr;
+    return getenv(name);
+}
+
 int build_cnn(apr_engine *e, const ParsedModel &pm)
 {
     if (pm.n_classes < 1 || pm.n_classes > APR_MAX_CLASSES) { e->err = "class count out of range"; return APR_ERR_MODEL; }
@@ -349,18 +359,18 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     if (pm.features > 1024 || pm.features % 4) { e->err = "unsupported classifier width"; return APR_ERR_MODEL; }
     int h = kNmels, w = kSpecFrames, rc;
     size_t act_max = 0, v_max = 0, m_max = 0, part_max = 0;
-    const char *senv = getenv("APR_SPLITK");
+    const char *senv = dev_getenv("APR_SPLITK");
     const bool splitk_on = !(senv && senv[0] == '0');
     // APR_WINOGRAD=0 disables the Winograd path; APR_WINO_MIN_CIN moves its channel threshold
-    const char *wenv = getenv("APR_WINOGRAD");
+    const char *wenv = dev_getenv("APR_WINOGRAD");
     const bool wino_on = !(wenv && wenv[0] == '0');
-    const char *cenv = getenv("APR_WINO_MIN_CIN");
+    const char *cenv = dev_getenv("APR_WINO_MIN_CIN");
     const int wino_min_cin = cenv ? atoi(cenv) : 128;
     // the one-kernel form (wino_fused.hip.h) wins while K = Cin is short; APR_WINO_FUSED=0 turns it
     // off, APR_WINO_FUSED_MAX_CIN moves its upper channel bound
-    const char *fenv = getenv("APR_WINO_FUSED");
+    const char *fenv = dev_getenv("APR_WINO_FUSED");
     const bool fused_on = wino_on && !(fenv && fenv[0] == '0');
-    const char *fcenv = getenv("APR_WINO_FUSED_MAX_CIN");
+    const char *fcenv = dev_getenv("APR_WINO_FUSED_MAX_CIN");
     // Cin = 512 (layers 9, 11): the one-kernel form wins once a pass holds enough tiles to fill the chip (measured at
     // 2048 windows: 58.0 vs 67.6 ms and 29.0 vs 31.9 ms a step); small engines keep transform kernels + batched GEMM there
     // one-clip engines (max_batch <= 4): 24 or 16 work units of layers 5 and 7 leave the chip idle while each walks 16 or 32 K
@@ -368,15 +378,15 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     // Stride-2 layers in polyphase Winograd F(2,2) form (wino_s2.hip.h): 25/36 of the products, against a round trip of
     // M[25][T][Cout] through HBM -- pays where Cin is large and a pass is big enough to fill the 25 GEMM grids.
     // APR_WINO_S2=0 turns it off; APR_WINO_S2_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests).
-    const char *s2env = getenv("APR_WINO_S2");
+    const char *s2env = dev_getenv("APR_WINO_S2");
     const bool wino_s2_on = wino_on && !(s2env && s2env[0] == '0');
     // Passes of >= 1024 windows: layers 6, 8 and 10 (Cin >= 256, >= 24 pixels a window; measured 105.6 vs 116.4, 95.4 vs 115.5
     // and 24.1 vs 29.4 ms a step; layer 4 loses 10 ms, layer 12 pads 2x3 pixels to 2x4).  Passes of 128..1023 windows (live
     // mode): layers 6 to 12 -- there the direct kernel's grids are short (layer 12 at 256 windows: 192 workgroups of 576 K steps).
     const bool s2_big = e->max_batch >= 1024;
-    const int wino_s2_min_cin = getenv("APR_WINO_S2_MIN_CIN") ? atoi(getenv("APR_WINO_S2_MIN_CIN")) : 256;
-    const int wino_s2_min_px = getenv("APR_WINO_S2_MIN_PX") ? atoi(getenv("APR_WINO_S2_MIN_PX")) : (s2_big ? 24 : 1);
-    const int wino_s2_min_batch = getenv("APR_WINO_S2_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_MIN_BATCH")) : 128;
+    const int wino_s2_min_cin = dev_getenv("APR_WINO_S2_MIN_CIN") ? atoi(dev_getenv("APR_WINO_S2_MIN_CIN")) : 256;
+    const int wino_s2_min_px = dev_getenv("APR_WINO_S2_MIN_PX") ? atoi(dev_getenv("APR_WINO_S2_MIN_PX")) : (s2_big ? 24 : 1);
+    const int wino_s2_min_batch = dev_getenv("APR_WINO_S2_MIN_BATCH") ? atoi(dev_getenv("APR_WINO_S2_MIN_BATCH")) : 128;
     const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
@@ -420,12 +430,12 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             std::vector<float> u((size_t)16 * cv.cin * cv.cout);
             wf_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
-            const char *wv = getenv("APR_WINO_FUSED_WAVES");   // developer knob: 4 = the four-wave kernel
+            const char *wv = dev_getenv("APR_WINO_FUSED_WAVES");   // developer knob: 4 = the four-wave kernel
             L.wino = 3;
             // unit order (wf_unit): N tiles in groups of four.  HBM fetch of a 2048-window pass, all N tiles of an M tile side by
             // side -> groups of four: layer 7 7.9 -> 4.9 GB, layer 9 3.7 -> 2.4, layer 11 3.3 -> 1.2 (groups of two: the same;
             // of one: 7.3 / 3.6 / 1.8 and twice the input on the layers of few N tiles); the times do not move (tools/gn_sweep.sh)
-            L.gn = getenv("APR_WINO_GN") ? atoi(getenv("APR_WINO_GN")) : 4;
+            L.gn = dev_getenv("APR_WINO_GN") ? atoi(dev_getenv("APR_WINO_GN")) : 4;
             L.fused_waves = wv && atoi(wv) == 4 ? 4 : 8;
             L.ksplit = 1;
             L.th = (L.hout + 1) / 2;
@@ -456,7 +466,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
             // one-clip engines: a few dozen workgroups with Cin / 16 K steps each; split K (>= 4 steps a split) towards 512
             if (splitk_on && e->max_batch <= 4) {
                 const long long blocks = ((t_full + L.wbm_tile - 1) / L.wbm_tile) * (cv.cout / 128) * 16;
-                const char *wsenv = getenv("APR_WSPLIT_MAX");   // developer knob
+                const char *wsenv = dev_getenv("APR_WSPLIT_MAX");   // developer knob
                 const long long wsmax = wsenv ? atoi(wsenv) : 4;
                 L.wsplit = (int)std::max<long long>(1, std::min<long long>(std::min<long long>(512 / std::max<long long>(blocks, 1), cv.cin / 16 / 4), wsmax));
             }
@@ -468,18 +478,18 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
         // nine-sum GEMMs + output transform, 30.6 direct; 256 live streams: 8.8 against 9.0 ms a tick);
         // APR_WINO_S2_FUSED=0 turns it off, APR_WINO_S2_FUSED_MIN_CIN / _MIN_PX / _MIN_BATCH move its bounds (developer knobs, tests)
         {
-            const char *sfenv = getenv("APR_WINO_S2_FUSED");
+            const char *sfenv = dev_getenv("APR_WINO_S2_FUSED");
             const bool s2f_on = wino_s2_on && !(sfenv && sfenv[0] == '0');
-            const int s2f_min_cin = getenv("APR_WINO_S2_FUSED_MIN_CIN") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_CIN")) : 128;
-            const int s2f_min_px = getenv("APR_WINO_S2_FUSED_MIN_PX") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_PX")) : 1;
-            const int s2f_min_batch = getenv("APR_WINO_S2_FUSED_MIN_BATCH") ? atoi(getenv("APR_WINO_S2_FUSED_MIN_BATCH")) : 128;
+            const int s2f_min_cin = dev_getenv("APR_WINO_S2_FUSED_MIN_CIN") ? atoi(dev_getenv("APR_WINO_S2_FUSED_MIN_CIN")) : 128;
+            const int s2f_min_px = dev_getenv("APR_WINO_S2_FUSED_MIN_PX") ? atoi(dev_getenv("APR_WINO_S2_FUSED_MIN_PX")) : 1;
+            const int s2f_min_batch = dev_getenv("APR_WINO_S2_FUSED_MIN_BATCH") ? atoi(dev_getenv("APR_WINO_S2_FUSED_MIN_BATCH")) : 128;
             if (!L.wino && s2f_on && tdim_ok && l > 0 && cv.stride == 2 && cv.cin >= s2f_min_cin && cv.cin % 32 == 0 && cv.cout % WS_BN == 0 &&
                 L.hout * L.wout >= s2f_min_px && e->max_batch >= s2f_min_batch) {
                 std::vector<float> u((size_t)16 * cv.cin * cv.cout);
                 ws_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
                 if ((rc = dev_upload(e, &L.d_u, u))) return rc;
                 L.wino = 5;
-                L.gn = getenv("APR_WINO_S2_GN") ? atoi(getenv("APR_WINO_S2_GN")) : 4;   // layer 12: 4.5 -> 1.9 GB, layer 10: 2.0 -> 1.6
+                L.gn = dev_getenv("APR_WINO_S2_GN") ? atoi(dev_getenv("APR_WINO_S2_GN")) : 4;   // layer 12: 4.5 -> 1.9 GB, layer 10: 2.0 -> 1.6
                 L.ksplit = 1;
                 L.th = (L.hout + 1) / 2;
                 L.tw = (L.wout + 1) / 2;
@@ -504,7 +514,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     }
     // layers 1 + 2 in one kernel when they are the reference's (1 -> 32 stride 1, 32 -> 64 stride 2); APR_FUSE12=0: two kernels
     // (latency engines keep the two kernels: 48 tiles of one clip leave most CUs idle and measured 20 us slower)
-    if (e->layers.size() >= 2 && e->max_batch > 4 && !(getenv("APR_FUSE12") && atoi(getenv("APR_FUSE12")) == 0)) {
+    if (e->layers.size() >= 2 && e->max_batch > 4 && !(dev_getenv("APR_FUSE12") && atoi(dev_getenv("APR_FUSE12")) == 0)) {
         const Layer &a = e->layers[0];
         Layer &b = e->layers[1];
         if (a.cin == 1 && a.cout == 32 && a.stride == 1 && b.cin == 32 && b.cout == 64 && b.stride == 2 && !b.wino) {
@@ -990,7 +1000,7 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
         rc = APR_ERR_DEVICE;
     }
     {
-        const char *genv = getenv("APR_GRAPH");   // APR_GRAPH=0: small calls launch kernel by kernel too
+        const char *genv = dev_getenv("APR_GRAPH");   // APR_GRAPH=0: small calls launch kernel by kernel too
         e->graph_on = !(genv && genv[0] == '0');
     }
     if (!rc) rc = build_frontend(e);

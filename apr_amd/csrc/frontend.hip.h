@@ -27,7 +27,7 @@ constexpr int kSampleBytes = 192000;
 #define APR_FE_FPB 8
 #endif
 constexpr int kFramesPerBlock = APR_FE_FPB;    // frames per workgroup = its waves (one frame per wave): the tables a workgroup stages in LDS
-                                      // serve eight frames; 56 KB of LDS = two workgroups, 16 waves per CU
+                                      // serve eight frames; 61 KB of LDS (62 464 B, asserted below) = two workgroups, 16 waves per CU
 constexpr int kMaxNnz = 2304;         // CSR capacity (go lens: 1892, librosa: ~2.1k)
 constexpr int kMaxNnzPad = 2688;      // the same with every band widened to whole quads of bins starting at a multiple of 4
 
@@ -133,6 +133,12 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) __attribute__((amdgpu_waves_p
     __shared__ __attribute__((aligned(16))) float s_w[kMaxNnzPad];   // band weights, every band padded to whole aligned quads of bins
     __shared__ float2 s_tw[1024];                                    // W_2048^i, i < 1024: the post-process reads consecutive entries
     __shared__ float2 s_tw23[1024];                                  // passes 2 and 3, lane-major (FrontendTables::tw23): no bank conflicts
+    // the four arrays above: 8 x 1104 x 4 + 2688 x 4 + 8192 + 8192 = 62 464 B.  Static LDS is capped at 64 KB per workgroup, and
+    // the launch shape (two workgroups = 16 waves per CU) needs twice that inside the CU's 160 KB: raising kMaxNnzPad,
+    // kLdsPlane or APR_FE_FPB past either bound must fail here, not drop occupancy silently.
+    constexpr size_t kFeLdsBytes = sizeof(float) * kFramesPerBlock * kLdsPlane + sizeof(float) * kMaxNnzPad + 2 * sizeof(float2) * 1024;
+    static_assert(kFeLdsBytes <= 65536, "stft_mel_kernel: static LDS over the 64 KB workgroup limit");
+    static_assert(2 * kFeLdsBytes <= 160 * 1024, "stft_mel_kernel: two workgroups no longer fit one CU's 160 KB of LDS");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < T.nnz_pad / 4; i += NT) reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(T.mel_wp)[i];

@@ -28,6 +28,7 @@ import (
 
 	"crypto/sha256"
 	"runtime"
+	"sort"
 	"sync"
 	"unsafe"
 
@@ -41,6 +42,9 @@ import (
 // RawBytes, not its address: a model re-loaded after retraining has the same length and may be
 // handed the old address by the allocator.  The digest of a slice is memoised by (address, len)
 // together with the slice itself, so that address cannot be reused while the memo entry lives.
+// The memo is BOUNDED (maxDigests entries, oldest dropped first): a daemon that re-loads its models after
+// every retraining without calling Unload would otherwise keep 94 MB of every file it ever loaded alive.
+// A dropped entry only costs one more sha256 of that model on its next call.
 type engine struct {
 	mu sync.Mutex
 	h  *C.apr_engine
@@ -61,12 +65,32 @@ type digestMemo struct {
 var (
 	cacheMu   sync.Mutex
 	frontEnds = map[int]*engine{}       // Prepare, Upsample3: one per device
-	engines   = map[engineKey]*engine{} // Infer (max_batch 1), ScoreBatch / SweepFiles (2048), StreamScorer (n streams)
+	engines   = map[engineKey]*engine{} // Infer (max_batch 1), ScoreBatch / SweepFiles (batchWindows), StreamScorer (n streams)
 	digests   = map[uintptr]digestMemo{}
-	// Device is the GPU the package-level calls use (Prepare, Infer, ScoreBatch, SweepFiles, StreamScorer); set it
-	// before the first call, e.g. from a config key.  SweepFilesMulti takes its own device list.
-	Device = 0
+	digestAge []uintptr // insertion order of digests' keys, oldest first
+	device    = 0       // guarded by cacheMu: SetDevice / currentDevice
 )
+
+const (
+	maxDigests = 8 // models whose bytes the memo may keep alive (inspect_models is a handful)
+	// windows per GPU pass of ScoreBatch / SweepFiles / SweepFilesMulti: every measurement of the engine is at 4096
+	// (bench.py --max-batch; 30 GB of activations out of 288)
+	batchWindows = 4096
+)
+
+// SetDevice selects the GPU the package-level calls use (Prepare, Infer, ScoreBatch, SweepFiles, StreamScorer); call it
+// before the first of them, e.g. from a config key.  SweepFilesMulti takes its own device list.
+func SetDevice(d int) {
+	cacheMu.Lock()
+	device = d
+	cacheMu.Unlock()
+}
+
+func currentDevice() int {
+	cacheMu.Lock()
+	defer cacheMu.Unlock()
+	return device
+}
 
 func lastErr(h *C.apr_engine) string { return C.GoString(C.apr_last_error(h)) }
 
@@ -89,22 +113,22 @@ func createEngine(raw []byte, device, maxBatch int) (*C.apr_engine, string) {
 func frontend() *engine {
 	cacheMu.Lock()
 	defer cacheMu.Unlock()
-	fe := frontEnds[Device]
+	fe := frontEnds[device]
 	if fe == nil {
-		h, why := createEngine(nil, Device, 64)
+		h, why := createEngine(nil, device, 64)
 		if h == nil {
 			log.Die("GPU front end unavailable: %s", why)
 		}
 		fe = &engine{h: h}
-		frontEnds[Device] = fe
+		frontEnds[device] = fe
 	}
 	return fe
 }
 
-func engineFor(m OnnxModel) *engine { return cachedEngine(m, 1, Device) }
+func engineFor(m OnnxModel) *engine { return cachedEngine(m, 1, currentDevice()) }
 
-// batchEngineFor: the engine of ScoreBatch / SweepFiles (2048 windows per GPU pass).
-func batchEngineFor(m OnnxModel) *engine { return cachedEngine(m, 2048, Device) }
+// batchEngineFor: the engine of ScoreBatch / SweepFiles (batchWindows windows per GPU pass).
+func batchEngineFor(m OnnxModel) *engine { return cachedEngine(m, batchWindows, currentDevice()) }
 
 func digestOf(raw []byte) [32]byte { // cacheMu held
 	addr := uintptr(unsafe.Pointer(&raw[0]))
@@ -112,7 +136,14 @@ func digestOf(raw []byte) [32]byte { // cacheMu held
 		return d.digest
 	}
 	d := digestMemo{raw: raw, digest: sha256.Sum256(raw)}
+	if _, had := digests[addr]; !had {
+		digestAge = append(digestAge, addr)
+	}
 	digests[addr] = d
+	for len(digestAge) > maxDigests { // bounded: the oldest entry lets go of its model's bytes
+		delete(digests, digestAge[0])
+		digestAge = digestAge[1:]
+	}
 	return d.digest
 }
 
@@ -160,7 +191,14 @@ func Unload(m OnnxModel) int {
 			n++
 		}
 	}
-	delete(digests, uintptr(unsafe.Pointer(&m.RawBytes[0])))
+	addr := uintptr(unsafe.Pointer(&m.RawBytes[0]))
+	delete(digests, addr)
+	for i, a := range digestAge {
+		if a == addr {
+			digestAge = append(digestAge[:i], digestAge[i+1:]...)
+			break
+		}
+	}
 	return n
 }
 
@@ -263,7 +301,7 @@ type StreamScorer struct {
 }
 
 func NewStreamScorer(inferModel OnnxModel, nStreams int) *StreamScorer {
-	e := cachedEngine(inferModel, nStreams, Device)
+	e := cachedEngine(inferModel, nStreams, currentDevice())
 	empty := -1
 	for i, l := range inferModel.Labels {
 		if l == "empty" {
@@ -384,13 +422,28 @@ func SweepFilesMulti(inferModel OnnxModel, devices []int, files [][]byte, trust 
 	if nf == 0 || len(devices) == 0 {
 		return
 	}
+	// a device listed twice would list one handle twice: refused here, before any lock is taken
+	seen := map[int]bool{}
+	for _, d := range devices {
+		if seen[d] {
+			log.Die("Inference failed: SweepFilesMulti: device %d listed twice", d)
+		}
+		seen[d] = true
+	}
 	es := make([]*engine, len(devices))
 	hs := (*[1 << 16]*C.apr_engine)(C.malloc(C.size_t(len(devices)) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:len(devices):len(devices)]
 	defer C.free(unsafe.Pointer(&hs[0]))
 	for i, d := range devices {
-		es[i] = cachedEngine(inferModel, 2048, d) // the same device twice would list one handle twice: refused by the library
+		es[i] = cachedEngine(inferModel, batchWindows, d)
 		hs[i] = es[i].h
 	}
+	// ONE global lock order (ascending device id), whatever order the caller listed the devices in: two concurrent calls
+	// with [0,1] and [1,0], or a call overlapping a ScoreBatch / StreamScorer on one of these engines, cannot deadlock
+	order := make([]int, len(devices))
+	for i := range order {
+		order[i] = i
+	}
+	sort.Slice(order, func(a, b int) bool { return devices[order[a]] < devices[order[b]] })
 	empty := -1
 	for i, l := range inferModel.Labels {
 		if l == "empty" {
@@ -419,13 +472,13 @@ func SweepFilesMulti(inferModel OnnxModel, devices []int, files [][]byte, trust 
 	flat := make([]float64, total*nc+1)
 	label = make([]int32, total+1)
 	m := make([]uint8, total+1)
-	for _, e := range es {
-		e.mu.Lock()
+	for _, i := range order {
+		es[i].mu.Lock()
 	}
 	rc := C.apr_sweep_files_multi(&hs[0], C.int(len(devices)), C.int(nf), &ptrs[0], &lens[0], C.size_t(ffmpeg.BytesPerSecond), C.double(trust),
 		C.int(empty), (*C.double)(unsafe.Pointer(&flat[0])), (*C.int32_t)(unsafe.Pointer(&label[0])), (*C.uint8_t)(unsafe.Pointer(&m[0])), &cfirst[0])
-	for _, e := range es {
-		e.mu.Unlock()
+	for _, i := range order {
+		es[i].mu.Unlock()
 	}
 	if rc != 0 {
 		log.Die("Inference failed: %v", lastErr(es[0].h))

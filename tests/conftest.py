@@ -13,6 +13,11 @@ LABELS = ["big_dog", "combination", "empty", "small_dog"]  # src/model/test_mode
 CLIPS = ["test_empty", "test_smalldog", "test_bigdog", "test_combo"]  # src/model/model_test.go:54-71
 
 
+# the tests compare kernel forms through the library's developer switches (APR_WINOGRAD=0 ...); a release process ignores those
+# unless APR_DEV_KNOBS=1 (csrc/engine.hip: dev_getenv).  test_release_library_ignores_developer_switches checks the other side.
+os.environ["APR_DEV_KNOBS"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

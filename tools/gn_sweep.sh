@@ -2,7 +2,7 @@
 # Developer tool: HBM fetch (FETCH_SIZE) per Winograd layer and layer times for the unit-order group sizes (wf_unit):
 #   bash tools/gn_sweep.sh "0 1 2 4"
 R=$GRAFT_REPO_ROOT
-export TMPDIR=/tmp
+export TMPDIR=/tmp APR_DEV_KNOBS=1
 cd $R
 for gn in $1; do
   export APR_WINO_GN=$gn APR_WINO_S2_GN=$gn
