@@ -21,6 +21,7 @@
 #include "frontend.hip.h"
 #include "model_parse.h"
 #include "wino.hip.h"
+#include "wino4.hip.h"
 #include "resample.hip.h"
 #include "report.hip.h"
 #include "conv12_fused.hip.h"
@@ -68,7 +69,8 @@ struct Layer {
     // Winograd F(2x2,3x3) path (stride-1 layers with enough channels to amortise the transforms)
     int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2),
                             // 4 = stride 2 in polyphase Winograd F(2,2) form (wino_s2.hip.h: 25 GEMMs + output transform),
-                            // 5 = the same in one kernel (wino_s2_fused.hip.h)
+                            // 5 = the same in one kernel (wino_s2_fused.hip.h),
+                            // 6 = F(4x4,3x3) in three kernels (wino4.hip.h: 36 positions)
     int gn = 0;             // wino == 3 (8 waves), 5: N tiles per group in the unit order (wf_unit); 0 = all
     int fused_waves = 8;    // wino == 3: wino_fused8_f2 (8 waves a block) or wino_fused_f2 (4)
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
@@ -387,6 +389,13 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     const int wino_s2_min_cin = dev_getenv("APR_WINO_S2_MIN_CIN") ? atoi(dev_getenv("APR_WINO_S2_MIN_CIN")) : 256;
     const int wino_s2_min_px = dev_getenv("APR_WINO_S2_MIN_PX") ? atoi(dev_getenv("APR_WINO_S2_MIN_PX")) : (s2_big ? 24 : 1);
     const int wino_s2_min_batch = dev_getenv("APR_WINO_S2_MIN_BATCH") ? atoi(dev_getenv("APR_WINO_S2_MIN_BATCH")) : 128;
+    // F(4x4,3x3) in three kernels (wino4.hip.h), measured per 4096-window pass against the fused F(2x2) kernel (round 3,
+    // tools/batch_breakdown.py): layer 7 10.1 vs 12.8 ms, layer 9 4.4 vs 6.2, layer 11 2.8 vs 3.1 -- adopted from Cin = 256 on;
+    // layer 5 14.2 vs 13.5 and layer 3 22.8 vs 15.2 (the V / M round trips through HBM outweigh the 1.78x fewer multiplies): not.
+    // Passes of 256 windows (live mode): layers 7 / 9 / 11 = 0.70 / 0.32 / 0.22 ms against 0.88 / 0.53 / 0.26 (6.44 vs 6.85 ms a pass).
+    // One-clip engines keep their split-K forms.
+    const int f4_default_min_cin = e->max_batch >= 128 ? 256 : 1 << 30;
+    const int f4_min_batch = dev_getenv("APR_WINO_F4_MIN_BATCH") ? atoi(dev_getenv("APR_WINO_F4_MIN_BATCH")) : 1;
     const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
         const ConvSpec &cv = pm.convs[l];
@@ -426,7 +435,23 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
         if ((rc = dev_upload(e, &L.d_w, wt)) || (rc = dev_upload(e, &L.d_b, cv.b))) return rc;
         // (the fused kernels' tile arithmetic, wf_tile, is exact up to WF_MAX_TDIM tiles a side)
         const bool tdim_ok = (L.hout + 1) / 2 <= WF_MAX_TDIM && (L.wout + 1) / 2 <= WF_MAX_TDIM;
-        if (fused_on && tdim_ok && l > 0 && cv.stride == 1 && cv.cin % 16 == 0 && cv.cin >= 64 && cv.cin <= fused_max_cin && cv.cout % WF_BN == 0) {
+        // F(4x4,3x3), three kernels (wino4.hip.h): APR_WINO_F4_MIN_CIN .. APR_WINO_F4_MAX_CIN select the stride-1 layers (developer knobs)
+        const int f4_min_cin = dev_getenv("APR_WINO_F4_MIN_CIN") ? atoi(dev_getenv("APR_WINO_F4_MIN_CIN")) : f4_default_min_cin;
+        const int f4_max_cin = dev_getenv("APR_WINO_F4_MAX_CIN") ? atoi(dev_getenv("APR_WINO_F4_MAX_CIN")) : 4096;
+        if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= f4_min_cin && cv.cin <= f4_max_cin && cv.cin % 16 == 0 && cv.cout % 128 == 0 &&
+            e->max_batch >= f4_min_batch) {
+            std::vector<float> u((size_t)36 * cv.cin * cv.cout);
+            wino4_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
+            if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+            L.wino = 6;
+            L.ksplit = 1;
+            L.th = (L.hout + 3) / 4;
+            L.tw = (L.wout + 3) / 4;
+            const long long t_full = (long long)e->max_batch * L.th * L.tw;
+            L.wbm_tile = ((t_full + 127) / 128) * (cv.cout / 128) * 36 < 1024 ? 64 : 128;
+            v_max = std::max(v_max, (size_t)36 * L.th * L.tw * cv.cin);
+            m_max = std::max(m_max, (size_t)36 * L.th * L.tw * cv.cout);
+        } else if (fused_on && tdim_ok && l > 0 && cv.stride == 1 && cv.cin % 16 == 0 && cv.cin >= 64 && cv.cin <= fused_max_cin && cv.cout % WF_BN == 0) {
             std::vector<float> u((size_t)16 * cv.cin * cv.cout);
             wf_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
             if ((rc = dev_upload(e, &L.d_u, u))) return rc;
@@ -700,6 +725,32 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             {
                 ProfScope ps(e, L.slot_out, 0.0, 4.0 * (9.0 * T * L.cout + (double)M * L.cout));
                 hipLaunchKernelGGL(wino_s2_output, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
+                                   e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
+            }
+            in = out;
+            continue;
+        }
+        if (L.wino == 6) {
+            const long long T = (long long)batch * L.th * L.tw;
+            const long long nv = T * (L.cin / 4), nm = T * (L.cout / 4);
+            {
+                ProfScope ps(e, L.slot_in, 0.0, 4.0 * ((double)batch * L.hin * L.win * L.cin + 36.0 * T * L.cin));
+                hipLaunchKernelGGL(wino_input_f4, dim3((unsigned)std::min<long long>((nv + 255) / 256, 65536)), dim3(256), 0, e->stream, in,
+                                   e->d_V, L.hin, L.win, L.cin, L.th, L.tw, T);
+            }
+            {
+                ProfScope ps(e, L.slot, 2.0 * 36.0 * (double)T * L.cin * L.cout, 4.0 * 36.0 * ((double)T * (L.cin + L.cout) + (double)L.cin * L.cout));
+                const int tiles_n = L.cout / 128;
+                if (L.wbm_tile == 64)
+                    hipLaunchKernelGGL((conv3x3_igemm_f32<64, 128, 1, 1>), dim3((unsigned)(((T + 63) / 64) * tiles_n), 36, 1), dim3(256), 0, e->stream, e->d_V,
+                                       L.d_u, L.d_b, e->d_M, 1, 1, L.cin, 1, 1, L.cout, (int)T, tiles_n);
+                else
+                    hipLaunchKernelGGL((conv3x3_igemm_f32<128, 128, 1, 1>), dim3((unsigned)(((T + 127) / 128) * tiles_n), 36, 1), dim3(256), 0, e->stream, e->d_V,
+                                       L.d_u, L.d_b, e->d_M, 1, 1, L.cin, 1, 1, L.cout, (int)T, tiles_n);
+            }
+            {
+                ProfScope ps(e, L.slot_out, 0.0, 4.0 * (36.0 * T * L.cout + (double)M * L.cout));
+                hipLaunchKernelGGL(wino_output_f4, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
                                    e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
             }
             in = out;
@@ -1014,7 +1065,11 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
             else if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
             else if (L.wino == 5) snprintf(nm, sizeof nm, "wino_s2_fused");
             else if (L.wino == 4) snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 3>", L.wbm_tile);
-            else if (L.wino) {
+            else if (L.wino == 6) {
+                L.slot_in = e->n_slots;
+                add_slot(e, "wino_input_f4", (int)l + 1);
+                snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 1> x36", L.wbm_tile);
+            } else if (L.wino) {
                 L.slot_in = e->n_slots;
                 add_slot(e, "wino_input_f2", (int)l + 1);
                 snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 1>", L.wbm_tile);
@@ -1022,7 +1077,10 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
             else snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, %d, %d, %d>", L.bm_tile, L.bn_tile, L.stride, L.ksplit > 1 ? 2 : 0);
             L.slot = e->n_slots;
             add_slot(e, nm, (int)l + 1);
-            if (L.wino == 2) {
+            if (L.wino == 6) {
+                L.slot_out = e->n_slots;
+                add_slot(e, "wino_output_f4", (int)l + 1);
+            } else if (L.wino == 2) {
                 L.slot_out = e->n_slots;
                 add_slot(e, "wino_output_f2", (int)l + 1);
             } else if (L.wino == 4) {
