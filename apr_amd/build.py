@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libapr_amd.so")
 SOURCES = ["engine.hip", "model_parse.cpp", "synth.cpp", "ingest.cpp"]
-HEADERS = ["conv.hip.h", "frontend.hip.h", "wino.hip.h", "wino4.hip.h", "wino_fused.hip.h", "wino_fused8.hip.h", "wino_s2.hip.h", "wino_s2_fused.hip.h", "report.hip.h", "resample.hip.h", "conv12_fused.hip.h", "model_parse.h", os.path.join("..", "..", "include", "apr.h")]
+HEADERS = ["conv.hip.h", "frontend.hip.h", "wino.hip.h", "wino4.hip.h", "wino4_fused.hip.h", "wino_fused.hip.h", "wino_fused8.hip.h", "wino_s2.hip.h", "wino_s2_fused.hip.h", "report.hip.h", "resample.hip.h", "conv12_fused.hip.h", "model_parse.h", os.path.join("..", "..", "include", "apr.h")]
 
 
 def _hipcc() -> str:

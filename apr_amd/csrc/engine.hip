@@ -22,6 +22,7 @@
 #include "model_parse.h"
 #include "wino.hip.h"
 #include "wino4.hip.h"
+#include "wino4_fused.hip.h"
 #include "resample.hip.h"
 #include "report.hip.h"
 #include "conv12_fused.hip.h"
@@ -70,7 +71,8 @@ struct Layer {
     int wino = 0;           // 0 = direct implicit GEMM, 2 = F(2x2,3x3) in three kernels, 3 = in one (wino_fused*_f2),
                             // 4 = stride 2 in polyphase Winograd F(2,2) form (wino_s2.hip.h: 25 GEMMs + output transform),
                             // 5 = the same in one kernel (wino_s2_fused.hip.h),
-                            // 6 = F(4x4,3x3) in three kernels (wino4.hip.h: 36 positions)
+                            // 6 = F(4x4,3x3) in three kernels (wino4.hip.h: 36 positions),
+                            // 7 = F(4x4,3x3) in two: packed input transform + GEMMs with the output transform (wino4_fused.hip.h)
     int gn = 0;             // wino == 3 (8 waves), 5: N tiles per group in the unit order (wf_unit); 0 = all
     int fused_waves = 8;    // wino == 3: wino_fused8_f2 (8 waves a block) or wino_fused_f2 (4)
     float *d_u = nullptr;   // [16][cin][cout] = G g G^T (wino == 2), or wf_pack_u's image (wino == 3, fused kernel)
@@ -360,7 +362,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     if (3 * (int)pm.convs.size() + 3 > APR_PROF_SLOTS) { e->err = "too many conv layers"; return APR_ERR_MODEL; }
     if (pm.features > 1024 || pm.features % 4) { e->err = "unsupported classifier width"; return APR_ERR_MODEL; }
     int h = kNmels, w = kSpecFrames, rc;
-    size_t act_max = 0, v_max = 0, m_max = 0, part_max = 0;
+    size_t act_max = 0, v_max = 0, m_max = 0, part_max = 0, v_pad = 0;
     const char *senv = dev_getenv("APR_SPLITK");
     const bool splitk_on = !(senv && senv[0] == '0');
     // APR_WINOGRAD=0 disables the Winograd path; APR_WINO_MIN_CIN moves its channel threshold
@@ -395,6 +397,13 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     // Passes of 256 windows (live mode): layers 7 / 9 / 11 = 0.70 / 0.32 / 0.22 ms against 0.88 / 0.53 / 0.26 (6.44 vs 6.85 ms a pass).
     // One-clip engines keep their split-K forms.
     const int f4_default_min_cin = e->max_batch >= 128 ? 256 : 1 << 30;
+    // F(4x4,3x3) in two kernels (wino4_fused.hip.h: packed input transform, then the 36 GEMMs with the output transform in
+    // their kernel), measured per 4096-window pass, input transform included: layer 3 14.6 ms (fused F(2x2) 15.2), layer 5 10.3 (13.5),
+    // layer 7 8.4 (three-kernel F(4x4) 10.1), layer 9 4.0 (4.4), layer 11 2.5 (2.8): every stride-1 layer from 3 on in engines of
+    // >= 1024 windows.  Passes of 256 windows: layers 3 / 5 / 7 = 0.93 / 0.71 / 0.61 ms against 0.99 / 0.93 / 0.70, but layers 9 / 11
+    // (24 / 8 M tiles: fewer units than CUs) 0.36 / 0.32 against 0.32 / 0.22 in three kernels: up to Cin = 256 there.
+    const int f4f_default_min_cin = e->max_batch >= 128 ? 64 : 1 << 30;
+    const int f4f_default_max_cin = e->max_batch >= 1024 ? 512 : 256;
     const int f4_min_batch = dev_getenv("APR_WINO_F4_MIN_BATCH") ? atoi(dev_getenv("APR_WINO_F4_MIN_BATCH")) : 1;
     const int fused_max_cin = fcenv ? atoi(fcenv) : (e->max_batch >= 1024 ? 512 : e->max_batch <= 4 ? 64 : 256);
     for (size_t l = 0; l < pm.convs.size(); l++) {
@@ -438,7 +447,22 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
         // F(4x4,3x3), three kernels (wino4.hip.h): APR_WINO_F4_MIN_CIN .. APR_WINO_F4_MAX_CIN select the stride-1 layers (developer knobs)
         const int f4_min_cin = dev_getenv("APR_WINO_F4_MIN_CIN") ? atoi(dev_getenv("APR_WINO_F4_MIN_CIN")) : f4_default_min_cin;
         const int f4_max_cin = dev_getenv("APR_WINO_F4_MAX_CIN") ? atoi(dev_getenv("APR_WINO_F4_MAX_CIN")) : 4096;
-        if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= f4_min_cin && cv.cin <= f4_max_cin && cv.cin % 16 == 0 && cv.cout % 128 == 0 &&
+        // the two-kernel form (wino4_fused.hip.h): APR_WINO_F4F_MIN_CIN .. APR_WINO_F4F_MAX_CIN
+        const int f4f_min_cin = dev_getenv("APR_WINO_F4F_MIN_CIN") ? atoi(dev_getenv("APR_WINO_F4F_MIN_CIN")) : f4f_default_min_cin;
+        const int f4f_max_cin = dev_getenv("APR_WINO_F4F_MAX_CIN") ? atoi(dev_getenv("APR_WINO_F4F_MAX_CIN")) : f4f_default_max_cin;
+        if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= f4f_min_cin && cv.cin <= f4f_max_cin && cv.cin % W4_BK == 0 && cv.cout % W4_BN == 0 &&
+            (L.hout + 3) / 4 <= WF_MAX_TDIM && (L.wout + 3) / 4 <= WF_MAX_TDIM && e->max_batch >= f4_min_batch) {
+            std::vector<float> u((size_t)36 * cv.cin * cv.cout);
+            w4_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
+            if ((rc = dev_upload(e, &L.d_u, u))) return rc;
+            L.wino = 7;
+            L.gn = dev_getenv("APR_WINO_GN") ? atoi(dev_getenv("APR_WINO_GN")) : 4;
+            L.ksplit = 1;
+            L.th = (L.hout + 3) / 4;
+            L.tw = (L.wout + 3) / 4;
+            v_max = std::max(v_max, (size_t)36 * L.th * L.tw * cv.cin);
+            v_pad = std::max(v_pad, (size_t)36 * W4_TT * cv.cin);      // the last unit's rows past T
+        } else if (wino_on && l > 0 && cv.stride == 1 && cv.cin >= f4_min_cin && cv.cin <= f4_max_cin && cv.cin % 16 == 0 && cv.cout % 128 == 0 &&
             e->max_batch >= f4_min_batch) {
             std::vector<float> u((size_t)36 * cv.cin * cv.cout);
             wino4_pack_u(cv.w.data(), cv.cin, cv.cout, u.data());
@@ -554,7 +578,7 @@ int build_cnn(apr_engine *e, const ParsedModel &pm)
     for (int i = 0; i < 2; i++)
         if ((rc = dev_alloc(e, &e->d_act[i], act_max * (size_t)e->max_batch))) return rc;
     if (part_max && (rc = dev_alloc(e, &e->d_part, part_max))) return rc;
-    if (v_max && (rc = dev_alloc(e, &e->d_V, v_max * (size_t)e->max_batch))) return rc;
+    if (v_max && (rc = dev_alloc(e, &e->d_V, v_max * (size_t)e->max_batch + v_pad))) return rc;
     if (m_max && (rc = dev_alloc(e, &e->d_M, m_max * (size_t)e->max_batch))) return rc;
     return APR_OK;
 }
@@ -726,6 +750,28 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
                 ProfScope ps(e, L.slot_out, 0.0, 4.0 * (9.0 * T * L.cout + (double)M * L.cout));
                 hipLaunchKernelGGL(wino_s2_output, dim3((unsigned)std::min<long long>((nm + 255) / 256, 65536)), dim3(256), 0, e->stream,
                                    e->d_M, L.d_b, out, L.hout, L.wout, L.cout, L.th, L.tw, T);
+            }
+            in = out;
+            continue;
+        }
+        if (L.wino == 7) {
+            const long long T = (long long)batch * L.th * L.tw;
+            {
+                const long long n_blocks = ((T + W4_TT - 1) / W4_TT) * (L.cin / W4_BK);      // < 2^31: max_batch is capped at create
+                ProfScope ps(e, L.slot_in, 0.0, 4.0 * ((double)batch * L.hin * L.win * L.cin + 36.0 * T * L.cin));
+                hipLaunchKernelGGL(wino_input_f4p, dim3((unsigned)n_blocks), dim3(256), 0, e->stream, in,
+                                   e->d_V, L.hin, L.win, L.cin, L.th, L.tw, T, (int)n_blocks);
+            }
+            {
+                const int tiles_n = L.cout / W4_BN;
+                const long long tiles_m = (T + W4_TT - 1) / W4_TT;
+                ProfScope ps(e, L.slot, 2.0 * 36.0 * (double)T * L.cin * L.cout, 4.0 * (36.0 * T * L.cin + (double)M * L.cout + 36.0 * L.cin * L.cout));
+                W4Args wa;
+                wa.vp = e->d_V; wa.up = L.d_u; wa.bias = L.d_b; wa.out = out;
+                wa.H = L.hout; wa.W = L.wout; wa.Cin = L.cin; wa.Cout = L.cout; wa.th = L.th; wa.tw = L.tw; wa.T = (int)T; wa.tiles_n = tiles_n;
+                wa.mg = wf_magic(tiles_n, L.th, L.tw, tiles_m, L.gn);
+                wa.n_units = (int)(tiles_m * tiles_n);
+                hipLaunchKernelGGL(wino4_fused_out, dim3(wf8_grid(wa.n_units, e->n_cus)), dim3(512), W4_LDS_BYTES, e->stream, wa);
             }
             in = out;
             continue;
@@ -1042,6 +1088,10 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
     }
     if (!rc && (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || e->n_cus < 1)) e->n_cus = 256;
     if (!rc && !resolve_scratch(device_id, e->err)) rc = APR_ERR_DEVICE;   // this device's address of the static scratch array
+    if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(wino4_fused_out), hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES) != hipSuccess) {
+        e->err = "could not reserve LDS for wino4_fused_out";
+        rc = APR_ERR_DEVICE;
+    }
     if (!rc && hipFuncSetAttribute(reinterpret_cast<const void *>(wino_s2_fused), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess) {
         e->err = "could not reserve LDS for wino_s2_fused";
         rc = APR_ERR_DEVICE;
@@ -1065,7 +1115,11 @@ static int engine_create(const void *model_bytes, size_t n, int device_id, int m
             else if (L.wino == 3) snprintf(nm, sizeof nm, L.fused_waves == 4 ? "wino_fused_f2" : "wino_fused8_f2");
             else if (L.wino == 5) snprintf(nm, sizeof nm, "wino_s2_fused");
             else if (L.wino == 4) snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 3>", L.wbm_tile);
-            else if (L.wino == 6) {
+            else if (L.wino == 7) {
+                L.slot_in = e->n_slots;
+                add_slot(e, "wino_input_f4p", (int)l + 1);
+                snprintf(nm, sizeof nm, "wino4_fused_out");
+            } else if (L.wino == 6) {
                 L.slot_in = e->n_slots;
                 add_slot(e, "wino_input_f4", (int)l + 1);
                 snprintf(nm, sizeof nm, "conv3x3_igemm_f32<%d, 128, 1, 1> x36", L.wbm_tile);

@@ -1,0 +1,368 @@
+// wino4_fused.hip.h -- Winograd F(4x4, 3x3), stride 1, in TWO kernels: neither M nor the output transform touch HBM.
+//
+//   wino_input_f4p   d (NHWC) -> V = B^T d B, written in the consumer's LDS image order (below)
+//   wino4_fused_out  the 36 position GEMMs M[pos] = V[pos] x U[pos], the output transform A^T M A, + bias, ReLU, NHWC store
+//
+// Why two kernels and not one (wino_fused8_f2's form): a 6x6 patch IS its V (36 values either way), so a kernel that loads V
+// moves the same bytes into the CU as one that loads patches, and the K loop then holds no VALU work at all -- fp32 VALU
+// and fp32 MFMA do not overlap on this chip, and F(4x4) has 4x the transform arithmetic per MFMA of F(2x2).
+// Why not 36 positions side by side: 36 x (64 tiles x 64 channels) accumulators are 2.25x the register file.  The output
+// transform is linear in the positions, so the unit is computed in SIX PASSES, one row i of the 6x6 positions each:
+// 6 position GEMMs (24 streams of 32x32 blocks over 8 waves: 48 accumulator registers a wave), then the pass's M goes through
+// LDS from the MFMA layout (wave = block x 3 positions) to the transform layout (wave = 8 tiles, lane = channel, all six
+// positions), where R[b] = sum_j A^T[b][j] M[i][j] and Y[a][b] += A^T[a][i] R[b] accumulate the unit's 16 outputs per
+// (tile, channel) in registers (128 a lane).  After pass 5: + bias, ReLU, one 256-B run per pixel and store instruction.
+//
+// Work unit = 64 tiles (1024 output pixels) x 64 channels, one persistent workgroup of 8 waves per CU (wf8_grid, wf_unit order).
+// K step = 16 input channels = one slab each of V and U: [sub 2][j 6][row 64][8 floats] = 24 KiB, host- / producer-packed in
+// exactly that order with wino_fused_f2's half-swizzle, so a step's operands are two contiguous 24-KiB LDS-DMA copies
+// (every wave moves 3 KiB of each) and every ds_read_b128 feeds four MFMAs conflict-free.  Double buffered, the DMA of step
+// s+2 (which may belong to the next pass or the next unit) issued at the top of step s into the slot step s-1 read: three slots,
+// one barrier a step.  The slot a pass's last step has read is that pass's exchange buffer.
+// LDS: 3 slots x 48 KiB + two tile tables 1 KiB = 145 KiB.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wino4.hip.h"
+#include "wino_fused8.hip.h"
+
+namespace apr {
+
+#ifndef W4_ABL
+#define W4_ABL 0   // developer timing ablations (wrong results): 1 no slab DMA after a unit's first, 2 no exchange through X, 4 no output stores, 8 no transform arithmetic
+#endif
+
+constexpr int W4_TT = 64;                        // tiles per unit
+constexpr int W4_BN = 64;                        // output channels per unit
+constexpr int W4_BK = 16;                        // input channels per K step
+constexpr int W4_SLAB = 2 * 6 * 64 * 8;          // floats of one operand slab (one pass row, one K step)
+constexpr int W4_SLOT = 2 * W4_SLAB;             // a K step's V slab + U slab = 48 KiB = the exchange buffer [3][64][64] f32
+constexpr int W4_LDS_BYTES = 3 * W4_SLOT * 4 + 2 * 64 * 8;
+static_assert(W4_LDS_BYTES <= 160 * 1024, "wino4_fused_out: LDS over the CU's 160 KiB");
+
+// element (row r of 64, channel c of the K step's 16) of position (i, j) of K step kc of M / N tile b, in floats
+__host__ __device__ __forceinline__ size_t w4_slab_index(int b, int i, int kc, int KC, int j, int r, int c)
+{
+    const int sub = c >> 3, cl = c & 7;
+    return ((((size_t)b * 6 + i) * KC + kc) * 2 + sub) * (6 * 512) + (size_t)j * 512 + r * 8 + ((((cl >> 2) ^ ((r >> 4) & 1)) * 4) + (cl & 3));
+}
+
+// Host: g [Cout][Cin][3][3] (OIHW, BN folded) -> U = G g G^T (f64, rounded once) in slab order
+inline void w4_pack_u(const float *w, int cin, int cout, float *up)
+{
+    static const double G[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int KC = cin / W4_BK;
+    for (int o = 0; o < cout; o++)
+        for (int c = 0; c < cin; c++) {
+            const float *g = &w[((size_t)o * cin + c) * 9];
+            double t[6][3];
+            for (int i = 0; i < 6; i++)
+                for (int k = 0; k < 3; k++) t[i][k] = G[i][0] * g[k] + G[i][1] * g[3 + k] + G[i][2] * g[6 + k];
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++)
+                    up[w4_slab_index(o / W4_BN, i, c / W4_BK, KC, j, o % W4_BN, c % W4_BK)] = (float)(t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2]);
+        }
+}
+
+// in [B][H][W][C] -> V in slab order; tile t = (b, ty, tx) covers input rows 4ty-1 .. 4ty+4 (pad 1).
+// One workgroup = one unit's 64 tiles x one K step's 16 channels = the 36 [sub][row][8] pieces of one (unit, kc): thread = (row, channel
+// quad), so four lanes read 64 contiguous bytes of a pixel and a wave's store instruction writes two 512-B runs (rows 16 w .. 16 w + 15 of
+// sub 0 and of sub 1).  Workgroups of one unit (kc = 0 .. KC-1) follow each other inside an XCD's contiguous run, so the 128-B lines
+// of a pixel that the KC workgroups share are fetched into one L2.
+// Rows of the last unit past T are never written: their products land in output rows that are never stored.
+__global__ __launch_bounds__(256) void wino_input_f4p(const float *__restrict__ in, float *__restrict__ Vp, int H, int W, int C, int th, int tw,
+                                                      long long T, int n_blocks)
+{
+    const int KC = C / W4_BK;
+    // XCD-aware order: workgroup blockIdx.x runs on XCD blockIdx.x % 8; give every XCD a contiguous run of logical blocks
+    const int q8 = n_blocks >> 3, r8 = n_blocks & 7, xcd = blockIdx.x & 7;
+    const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int bm = lb / KC, kc = lb - bm * KC;
+    const int row = threadIdx.x >> 2, quad = threadIdx.x & 3;
+    const long long t = (long long)bm * W4_TT + row;
+    if (t >= T) return;
+    const int c = kc * W4_BK + quad * 4;
+    const int tx = (int)(t % tw);
+    const long long r = t / tw;
+    const int ty = (int)(r % th);
+    const long long b = r / th;
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const float *base = in + (b * H * (long long)W) * C + c;
+    f32x4 tmp[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const int x = x0 + j;
+        f32x4 d[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int y = y0 + i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y >= 0 && y < H && x >= 0 && x < W) v = ld4(base + ((long long)y * W + x) * C);
+            d[i] = v;
+        }
+        wino4_bt(d[0], d[1], d[2], d[3], d[4], d[5], tmp[0][j], tmp[1][j], tmp[2][j], tmp[3][j], tmp[4][j], tmp[5][j]);
+    }
+    float *o0 = Vp + w4_slab_index(bm, 0, kc, KC, 0, row, quad * 4);
+    const size_t pass_stride = (size_t)KC * W4_SLAB;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        f32x4 v[6];
+        wino4_bt(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) st4(o0 + i * pass_stride + j * 512, v[j]);
+    }
+}
+
+struct W4Args {
+    const float *vp, *up, *bias;
+    float *out;
+    int H, W, Cin, Cout, th, tw, T, tiles_n;
+    WfMagic mg;
+    int n_units;
+};
+
+// exchange buffer X[3 positions][64 channels][16 quads of tiles][4]: the 16-B quad index is XOR-ed with the channel's low four bits, so
+// both the MFMA-side ds_write_b128 (a lane = a channel, four consecutive tile rows) and the transform-side ds_read_b128 (a lane =
+// a channel, a wave's eight tiles) spread eight consecutive lanes over all banks
+__device__ __forceinline__ int w4_x_index(int jj, int ch, int tile_quad) { return ((jj * 64 + ch) * 16 + (tile_quad ^ (ch & 15))) * 4; }
+
+__global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float w4_smem[];      // [3 slots][V slab, U slab]; a consumed slot doubles as the exchange buffer
+    unsigned *tbl = reinterpret_cast<unsigned *>(w4_smem + 3 * W4_SLOT);  // [2][64][2]: byte offset of the tile's pixel (0,0), mask of its pixels that exist
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = wave & 3, jh = wave >> 2;       // the wave's 32 x 32 block and its three positions of a pass (waves w, w + 4 share a SIMD and a block)
+    const int wm = blk >> 1, wn = blk & 1;
+    const int li = lane & 31, half = lane >> 5;
+    const int H = a.H, W = a.W, Cout = a.Cout, th = a.th, tw = a.tw, T = a.T;
+    const int KC = a.Cin / W4_BK, S = 6 * KC;       // K steps of a pass, steps of a unit (a multiple of 3: every unit starts in slot 0)
+
+    // persistent workgroups, XCD-aware (wino_fused8_f2): the units cut into 8 contiguous runs, one per XCD
+    const int per = gridDim.x >> 3, xcd = blockIdx.x & 7;
+    const int uq = a.n_units >> 3, ur = a.n_units & 7;
+    const int x_start = xcd < ur ? xcd * (uq + 1) : ur * (uq + 1) + (xcd - ur) * uq;
+    const int x_count = uq + (xcd < ur ? 1 : 0);
+    int lidl = blockIdx.x >> 3;
+    if (lidl >= x_count) return;
+
+    constexpr unsigned OOB = 0x80000000u;
+    i32x4 rsV, rsU, rsVn, rsUn;
+    rsV.z = rsU.z = rsVn.z = rsUn.z = 0x7FFFFFFF;
+    rsV.w = rsU.w = rsVn.w = rsUn.w = 0x00020000;
+#define W4_DESC(RV_, RU_, BM_, BN_)                                                                      \
+    {                                                                                                    \
+        const unsigned long long v_ = (unsigned long long)(a.vp + (size_t)(BM_) * S * W4_SLAB);          \
+        const unsigned long long u_ = (unsigned long long)(a.up + (size_t)(BN_) * S * W4_SLAB);          \
+        RV_.x = __builtin_amdgcn_readfirstlane((int)(unsigned)v_);                                       \
+        RV_.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(v_ >> 32) & 0xFFFF);                      \
+        RU_.x = __builtin_amdgcn_readfirstlane((int)(unsigned)u_);                                       \
+        RU_.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(u_ >> 32) & 0xFFFF);                      \
+    }
+    // a step's DMA: this wave's three 1-KiB pieces of the V slab and of the U slab, into slot SLOT_
+    const unsigned lds0 = (unsigned)(unsigned long long)w4_smem;
+    const unsigned dvoff = (unsigned)lane * 16u;
+#define W4_DMA(RV_, RU_, STEP_, SLOT_)                                                                   \
+    {                                                                                                    \
+        _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++)                                                 \
+        {                                                                                                \
+            const int pc_ = (3 * wave + p_) * 1024;                                                      \
+            lds_dma_b128(RV_, dvoff, __builtin_amdgcn_readfirstlane((STEP_) * (W4_SLAB * 4) + pc_),      \
+                         __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((SLOT_) * W4_SLOT * 4 + pc_))); \
+            lds_dma_b128(RU_, dvoff, __builtin_amdgcn_readfirstlane((STEP_) * (W4_SLAB * 4) + pc_),      \
+                         __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((SLOT_) * W4_SLOT + W4_SLAB) * 4 + pc_))); \
+        }                                                                                                \
+    }
+
+    // one 1-KiB piece: P_ = 0..2 of the V slab, 3..5 of the U slab
+#define W4_DMA1(RV_, RU_, STEP_, SLOT_, P_)                                                              \
+    {                                                                                                    \
+        const int pc_ = (3 * wave + ((P_) % 3)) * 1024;                                                  \
+        if ((P_) < 3)                                                                                    \
+            lds_dma_b128(RV_, dvoff, __builtin_amdgcn_readfirstlane((STEP_) * (W4_SLAB * 4) + pc_),      \
+                         __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((SLOT_) * W4_SLOT * 4 + pc_))); \
+        else                                                                                             \
+            lds_dma_b128(RU_, dvoff, __builtin_amdgcn_readfirstlane((STEP_) * (W4_SLAB * 4) + pc_),      \
+                         __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((SLOT_) * W4_SLOT + W4_SLAB) * 4 + pc_))); \
+    }
+    const int rd_sw = (half ^ ((li >> 4) & 1)) * 4;
+    const int rd_a = (3 * jh) * 512 + (wm * 32 + li) * 8 + rd_sw;          // floats into a slot: this wave's first position, its lane's row of V
+    const int rd_b = W4_SLAB + (3 * jh) * 512 + (wn * 32 + li) * 8 + rd_sw; // ... of U
+
+    int bm, bn;
+    wf_unit(x_start + lidl, a.mg, bm, bn);
+    W4_DESC(rsV, rsU, bm, bn)
+    W4_DMA(rsV, rsU, 0, 0)
+    W4_DMA(rsV, rsU, 1, 1)
+    int tb = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    for (;;) {
+        const int nl = lidl + per;
+        const bool more = nl < x_count;                 // workgroup-uniform
+        int bm_n, bn_n;
+        wf_unit(x_start + (more ? nl : lidl), a.mg, bm_n, bn_n);      // the last unit of a workgroup prefetches its own first steps again: staging nobody reads
+        W4_DESC(rsVn, rsUn, bm_n, bn_n)
+        const int g0 = bm * W4_TT;
+        const int b0 = wf_div(g0, a.mg.tpw);            // the unit's first window: output offsets are relative to it
+        if (tid < 64) {
+            unsigned off = OOB, mask = 0;
+            const int g = g0 + tid;
+            if (g < T) {
+                const WfUnitBase ub = wf_unit_base(g0, a.mg, th, tw);
+                int bb, ty, tx;
+                wf_tile(ub, tid, a.mg, th, tw, bb, ty, tx);
+                off = 4u * (unsigned)((((bb - b0) * H + 4 * ty) * W + 4 * tx) * Cout);
+#pragma unroll
+                for (int p = 0; p < 16; p++)
+                    if (4 * ty + (p >> 2) < H && 4 * tx + (p & 3) < W) mask |= 1u << p;
+            }
+            tbl[tb * 128 + 2 * tid] = off;
+            tbl[tb * 128 + 2 * tid + 1] = mask;
+        }
+        const int n = bn * W4_BN + lane;                // the lane's output channel in the transform layout
+        const float bv = a.bias[n];
+        float y[16][8];
+#pragma unroll
+        for (int p = 0; p < 16; p++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) y[p][e] = 0.0f;
+        __syncthreads();                                // step 0 of this unit is in slot 0 (every wave waited for its own pieces)
+
+        int s = 0, slot = 0;
+        for (int i = 0; i < 6; i++) {
+            f32x16 acc[3];
+            for (int kc = 0; kc < KC; kc++, s++) {
+                // the slabs of the step after next, now, into the slot the last step read (the steps past this unit's end are steps 0 and 1 of
+                // the workgroup's next unit)
+                // one 1-KiB piece ahead of every group of four MFMAs (issued together at the top of the step they cost 14 % of it)
+                const int slot2 = slot == 0 ? 2 : slot - 1;
+                i32x4 rsVs = rsV, rsUs = rsU;
+                int step2 = s + 2;
+                if (step2 >= S) { rsVs.x = rsVn.x; rsVs.y = rsVn.y; rsUs.x = rsUn.x; rsUs.y = rsUn.y; step2 -= S; }
+                if (kc == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[jj][e] = 0.0f;
+                }
+                const float *va = w4_smem + slot * W4_SLOT + rd_a;
+                const float *ub = w4_smem + slot * W4_SLOT + rd_b;
+                f32x4 af[2], bf[2];
+                af[0] = *reinterpret_cast<const f32x4 *>(va);
+                bf[0] = *reinterpret_cast<const f32x4 *>(ub);
+#pragma unroll
+                for (int g = 0; g < 6; g++) {           // g = 3 sub + jj
+                    if (!(W4_ABL & 1)) W4_DMA1(rsVs, rsUs, step2, slot2, g)
+                    if (g < 5) {
+                        const int o = ((g + 1) / 3) * (6 * 512) + ((g + 1) % 3) * 512;
+                        af[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(va + o);
+                        bf[(g + 1) & 1] = *reinterpret_cast<const f32x4 *>(ub + o);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        acc[g % 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][q], bf[g & 1][q], acc[g % 3], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kc == KC - 1) {
+                    // ---- the pass's M: MFMA layout -> transform layout through X = the slot this step read, three positions at a time ----
+                    float *X = w4_smem + slot * W4_SLOT;
+                    // the lane's exchange addresses, from scratch: computed once per kernel they are kept in (and spilled from) registers
+                    // across the K loops
+                    int lx = lane;
+                    asm volatile("" : "+v"(lx));
+                    const int lix = lx & 31, halfx = lx >> 5;
+                    // column i of A^T as scalars (rows 0 and 5 of M reach one output row each: the multiplications by 0 are kept, the
+                    // code is one straight line for every pass).  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+                    const float c0 = i < 5 ? 1.0f : 0.0f;
+                    const float c1 = (i == 1) ? 1.0f : (i == 2) ? -1.0f : (i == 3) ? 2.0f : (i == 4) ? -2.0f : 0.0f;
+                    const float c2 = (i == 1 || i == 2) ? 1.0f : (i == 3 || i == 4) ? 4.0f : 0.0f;
+                    const float c3 = (i == 1) ? 1.0f : (i == 2) ? -1.0f : (i == 3) ? 8.0f : (i == 4) ? -8.0f : (i == 5) ? 1.0f : 0.0f;
+#define W4_X_WRITE()                                                                                     \
+    _Pragma("unroll") for (int jj = 0; jj < 3; jj++)                                                     \
+        _Pragma("unroll") for (int e4 = 0; e4 < 4; e4++)                                                 \
+        {   /* accumulator registers 4 e4 .. 4 e4 + 3 = tile rows 8 e4 + 4 half + 0..3 of the block */   \
+            const f32x4 v_ = {acc[jj][4 * e4], acc[jj][4 * e4 + 1], acc[jj][4 * e4 + 2], acc[jj][4 * e4 + 3]}; \
+            *reinterpret_cast<f32x4 *>(X + w4_x_index(jj, wn * 32 + lix, wm * 8 + 2 * e4 + halfx)) = v_;   \
+        }
+                    if (!(W4_ABL & 2)) __syncthreads();  // every wave is done reading the slot
+                    if (jh == 0 && !(W4_ABL & 2)) { W4_X_WRITE() }
+                    if (!(W4_ABL & 2)) __syncthreads();
+                    // positions 0..2 of this wave's 8 tiles, folded at once: p0 = m0 + (m1 + m2), sp = m1 + m2, dp = m1 - m2
+                    float p0[8], sp[8], dp[8];
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; q2++) {
+                        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(0, lx, 2 * wave + q2));
+                        const f32x4 m1 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(1, lx, 2 * wave + q2));
+                        const f32x4 m2 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(2, lx, 2 * wave + q2));
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            sp[4 * q2 + k] = m1[k] + m2[k];
+                            dp[4 * q2 + k] = m1[k] - m2[k];
+                            p0[4 * q2 + k] = m0[k] + sp[4 * q2 + k];
+                        }
+                    }
+                    if (!(W4_ABL & 2)) __syncthreads();
+                    if (jh == 1 && !(W4_ABL & 2)) { W4_X_WRITE() }
+                    if (!(W4_ABL & 2)) __syncthreads();
+#undef W4_X_WRITE
+                    // positions 3..5, four tiles at a time: R[b] = sum_j A^T[b][j] M[i][j], then Y[a][b] += A^T[a][i] R[b]
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; q2++) {
+                        const f32x4 m3 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(0, lx, 2 * wave + q2));
+                        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(1, lx, 2 * wave + q2));
+                        const f32x4 m5 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(2, lx, 2 * wave + q2));
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int e = 4 * q2 + k;
+                            const float sq = m3[k] + m4[k], dq = m3[k] - m4[k];
+                            float R[4];
+                            R[0] = p0[e] + sq;
+                            R[1] = __builtin_fmaf(2.0f, dq, dp[e]);
+                            R[2] = __builtin_fmaf(4.0f, sq, sp[e]);
+                            R[3] = __builtin_fmaf(8.0f, dq, dp[e]) + m5[k];
+                            if (W4_ABL & 8) { y[0][e] += R[0] + R[1] + R[2] + R[3]; continue; }
+#pragma unroll
+                            for (int b = 0; b < 4; b++) {
+                                y[b][e] = __builtin_fmaf(c0, R[b], y[b][e]);
+                                y[4 + b][e] = __builtin_fmaf(c1, R[b], y[4 + b][e]);
+                                y[8 + b][e] = __builtin_fmaf(c2, R[b], y[8 + b][e]);
+                                y[12 + b][e] = __builtin_fmaf(c3, R[b], y[12 + b][e]);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // the next step's slabs have landed (the six DMAs issued at the top of this step may still be in flight).  Step 0 of a unit
+                // waits for everything: the unit before it has just issued its output stores, and loads and stores do not retire in one order
+                if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                __syncthreads();
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+        }
+        // ---- + bias, ReLU, store: lane = channel, so every store instruction writes one pixel's 64 channels (256 B) ----
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
+        const unsigned nb4 = 4u * (unsigned)n;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const unsigned off = tbl[tb * 128 + 2 * (8 * wave + e)], mask = tbl[tb * 128 + 2 * (8 * wave + e) + 1];
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                const unsigned o = ((mask >> p) & 1u) ? off + 4u * (unsigned)(((p >> 2) * W + (p & 3)) * Cout) + nb4 : OOB;
+                if (!(W4_ABL & 4) || y[p][e] == 12345.678f) wf_store1(rsO, o, wf_relu(y[p][e] + bv));
+            }
+        }
+        if (!more) break;
+        bm = bm_n; bn = bn_n; tb ^= 1; lidl = nl;
+        rsV.x = rsVn.x; rsV.y = rsVn.y; rsU.x = rsUn.x; rsU.y = rsUn.y;
+    }
+#undef W4_DESC
+#undef W4_DMA
+#undef W4_DMA1
+}
+
+}  // namespace apr

@@ -359,6 +359,40 @@ def test_winograd_f4_three_kernel_form(he_weights, monkeypatch):
     assert np.array_equal(run({"APR_WINO_F4_MIN_CIN": "64", "APR_SPLITK": "0"}), run({"APR_WINO_F4_MIN_CIN": "64", "APR_SPLITK": "0"}, batch=1))
 
 
+def test_winograd_f4_two_kernel_form(he_weights, monkeypatch):
+    # F(4x4,3x3) with the 36 GEMMs and the output transform in one kernel (wino4_fused.hip.h: six passes of six positions, M through
+    # LDS, Y accumulated in registers; V in slab order from wino_input_f4p) on every stride-1 layer from 3 on: against the reference's
+    # logits, against the three-kernel form (same products, the output transform summed in another order), ragged last units,
+    # many units per persistent workgroup, chunking
+    specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
+    want = np.load(os.path.join(GOLDEN, "cnn_logits_he_seed0.npy"))
+    blob = W.pack_blob(he_weights, 4)
+
+    def run(env, batch=8, x=specs):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = model.Engine(blob, 0, batch)
+        for k in env:
+            monkeypatch.delenv(k)
+        out = e.infer_logits(x)
+        e.close()
+        return out
+
+    f4f = {"APR_WINO_F4F_MIN_CIN": "64", "APR_WINO_F4F_MAX_CIN": "512", "APR_SPLITK": "0"}
+    two = run(f4f)
+    three = run({"APR_WINO_F4_MIN_CIN": "64", "APR_SPLITK": "0"})
+    print("F(4x4,3x3) two-kernel form, max logit error vs the reference's logits:", float(np.abs(two - want).max()), "vs the three-kernel form:", float(np.abs(two - three).max()))
+    assert np.abs(two - want).max() <= LOGIT_TOL
+    assert np.abs(two - three).max() <= 2e-5 and not np.array_equal(two, three)
+    assert np.array_equal(two, run(f4f, batch=1))                                   # chunking is bit-invisible
+    assert np.array_equal(two, run({**f4f, "APR_WINO_GN": "1"}))                    # so is the unit order
+    many = np.concatenate([specs] * 17)[:100]
+    big = run(f4f, batch=100, x=many)                                               # up to 150 units a layer: several per workgroup, ragged last unit
+    assert np.array_equal(big[:6], two) and np.array_equal(big[96:100], two[:4]) and np.array_equal(big[48:54], two)
+    only5 = run({"APR_WINO_F4F_MIN_CIN": "128", "APR_WINO_F4F_MAX_CIN": "128"})    # layer 5 alone (32 x 47 map: 8 x 12 tiles, last column ragged)
+    assert np.abs(only5 - want).max() <= LOGIT_TOL
+
+
 def test_stride2_polyphase_winograd_layers(he_weights, monkeypatch):
     # The stride-2 layers in polyphase Winograd F(2,2) form (wino_s2.hip.h; engines of max_batch >= 1024 use it on layers
     # 6, 8, 10).  Forced here on every stride-2 layer from 4 on in a small engine: odd widths (47 -> 24 tiles of 2), the
