@@ -24,7 +24,8 @@ SYMBOLS = (
     "apr_windows_in", "apr_sweep_files", "apr_wav_data_offset", "apr_bucket_hits",
     "apr_resample_taps", "apr_upsample", "apr_upsample_device", "apr_stream_tick", "apr_stream_buffer", "apr_stream_reset",
     "apr_prepare_batch_device_static", "apr_engine_create_ex", "apr_sweep_plan", "apr_sweep_files_multi",
-    "apr_bucket_hits_device",
+    "apr_bucket_hits_device", "apr_device_alloc", "apr_device_free", "apr_device_upload", "apr_device_download",
+    "apr_gather_rows_device",
 )
 
 
@@ -123,6 +124,17 @@ def lib():
     L.apr_bucket_hits.restype = C.c_int
     L.apr_bucket_hits_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_size_t, vp]
     L.apr_bucket_hits_device.restype = C.c_int
+    L.apr_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.apr_device_alloc.restype = C.c_int
+    L.apr_device_free.argtypes = [vp, vp]
+    L.apr_device_free.restype = C.c_int
+    L.apr_device_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.apr_device_upload.restype = C.c_int
+    L.apr_device_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.apr_device_download.restype = C.c_int
+    L.apr_gather_rows_device.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), vp, vp, vp]
+    L.apr_gather_rows_device.restype = C.c_int
     L.apr_resample_taps.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, vp]
     L.apr_resample_taps.restype = C.c_int
     L.apr_upsample.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, vp]

@@ -4,6 +4,8 @@
 // both reference flavours), weight ingest and re-layout, buffer management, kernel
 // launches on one HIP stream per engine, HIP-event profiling.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl is loaded with dlopen on first use (apr_gather_rows_device)
 
 #include <algorithm>
 #include <cmath>
@@ -11,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1575,6 +1578,173 @@ int apr_bucket_hits_device(apr_engine *e, const int32_t *d_label, const uint8_t 
                        (unsigned long long)windows_per_bucket, nb, d_hits);
     HIPCHK(e, hipGetLastError());
     return APR_OK;
+}
+
+int apr_device_alloc(apr_engine *e, size_t nbytes, void **d_out)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (!d_out) { e->err = "apr_device_alloc: null output pointer"; return APR_ERR_INVALID; }
+    *d_out = nullptr;
+    if (!nbytes) return APR_OK;
+    if (hipMalloc(d_out, nbytes) != hipSuccess) { (void)hipGetLastError(); *d_out = nullptr; e->err = "apr_device_alloc: out of device memory"; return APR_ERR_NOMEM; }
+    return APR_OK;
+}
+
+int apr_device_free(apr_engine *e, void *d_ptr)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (d_ptr) HIPCHK(e, hipFree(d_ptr));
+    return APR_OK;
+}
+
+int apr_device_upload(apr_engine *e, void *d_dst, const void *h_src, size_t nbytes)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (nbytes && (!d_dst || !h_src)) { e->err = "apr_device_upload: null pointer"; return APR_ERR_INVALID; }
+    if (!nbytes) return APR_OK;
+    HIPCHK(e, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return APR_OK;
+}
+
+int apr_device_download(apr_engine *e, void *h_dst, const void *d_src, size_t nbytes)
+{
+    int rc = check_engine(e);
+    if (rc) return rc;
+    if (nbytes && (!h_dst || !d_src)) { e->err = "apr_device_download: null pointer"; return APR_ERR_INVALID; }
+    if (!nbytes) return APR_OK;
+    HIPCHK(e, hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return APR_OK;
+}
+
+// ---- RCCL, loaded on first use: the library has no link-time dependency on it (a host that never gathers between GPUs, or a box without
+//      librccl, loads libapr_amd.so all the same), and a process that already holds an RCCL (PyTorch's) gets that one by its soname ----
+extern "C++" {
+namespace {
+struct RcclApi {
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+bool g_rccl_tried = false;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;   // device list -> its communicators; kept until the process ends
+
+const RcclApi &rccl_api()   // g_rccl_mu held
+{
+    if (g_rccl_tried) return g_rccl;
+    g_rccl_tried = true;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { g_rccl.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return g_rccl; }
+    auto sym = [&](const char *n) { void *p = dlsym(h, n); if (!p && g_rccl.why.empty()) g_rccl.why = std::string("librccl has no symbol ") + n; return p; };
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(sym("ncclCommInitAll"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
+    g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
+    g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    g_rccl.ok = g_rccl.why.empty();
+    return g_rccl;
+}
+}  // namespace
+}  // extern "C++"
+
+int apr_gather_rows_device(apr_engine *const *engines, int n_engines, int root, const size_t *n_rows, int n_classes,
+                           const double *const *d_probs, const int32_t *const *d_label, const uint8_t *const *d_match,
+                           double *d_probs_out, int32_t *d_label_out, uint8_t *d_match_out)
+{
+    if (!engines || n_engines < 1 || n_engines > 64 || root < 0 || root >= n_engines || !n_rows || n_classes < 1 || n_classes > APR_MAX_CLASSES) {
+        g_create_err = "apr_gather_rows_device: bad argument (1..64 engines, 0 <= root < n_engines, 1 <= n_classes <= 64)";
+        return APR_ERR_INVALID;
+    }
+    std::vector<int> devs(n_engines);
+    for (int i = 0; i < n_engines; i++) {
+        if (int rc = check_engine(engines[i])) { g_create_err = "apr_gather_rows_device: null engine"; return rc; }
+        devs[i] = engines[i]->device;
+        for (int j = 0; j < i; j++)
+            if (devs[j] == devs[i]) { engines[0]->err = g_create_err = "apr_gather_rows_device: two engines on one device (one rank per GPU)"; return APR_ERR_INVALID; }
+    }
+    apr_engine *er = engines[root];
+    // a tensor is gathered iff its output is given; then every engine with rows must give its part
+    struct Part { const void *const *src; void *dst; size_t elt; ncclDataType_t ty; };
+    const Part parts[3] = {{reinterpret_cast<const void *const *>(d_probs), d_probs_out, sizeof(double) * (size_t)n_classes, ncclUint8},
+                           {reinterpret_cast<const void *const *>(d_label), d_label_out, sizeof(int32_t), ncclUint8},
+                           {reinterpret_cast<const void *const *>(d_match), d_match_out, sizeof(uint8_t), ncclUint8}};
+    for (const Part &p : parts) {
+        if (!p.dst) continue;
+        for (int i = 0; i < n_engines; i++)
+            if (n_rows[i] && (!p.src || !p.src[i])) { er->err = "apr_gather_rows_device: an output is given but an engine's rows are missing"; return APR_ERR_INVALID; }
+    }
+    std::vector<ncclComm_t> comms;
+    const RcclApi *api = nullptr;
+    {   // also with one engine: the communicator is what a one-GPU box can still exercise
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        api = &rccl_api();
+        if (!api->ok) { er->err = "apr_gather_rows_device: " + api->why; return APR_ERR_DEVICE; }
+        auto it = g_rccl_comms.find(devs);
+        if (it == g_rccl_comms.end()) {
+            std::vector<ncclComm_t> c(n_engines);
+            const ncclResult_t r = api->CommInitAll(c.data(), n_engines, devs.data());
+            if (r != ncclSuccess) { er->err = std::string("ncclCommInitAll: ") + api->GetErrorString(r); return APR_ERR_DEVICE; }
+            it = g_rccl_comms.emplace(devs, std::move(c)).first;
+        }
+        comms = it->second;
+    }
+    // rows computed on each engine's stream are complete before anything is sent
+    for (int i = 0; i < n_engines; i++) {
+        HIPCHK(er, hipSetDevice(devs[i]));
+        HIPCHK(er, hipStreamSynchronize(engines[i]->stream));
+    }
+    int rc = APR_OK;
+    for (const Part &p : parts) {
+        if (!p.dst) continue;
+        ncclResult_t r = api->GroupStart();
+        size_t row0 = 0;
+        for (int i = 0; i < n_engines && r == ncclSuccess; i++) {
+            const size_t bytes = n_rows[i] * p.elt;
+            char *dst = static_cast<char *>(p.dst) + row0 * p.elt;
+            row0 += n_rows[i];
+            if (!bytes) continue;
+            if (i == root) {
+                if (hipSetDevice(devs[root]) != hipSuccess || hipMemcpyAsync(dst, p.src[i], bytes, hipMemcpyDeviceToDevice, er->stream) != hipSuccess) {
+                    er->err = "apr_gather_rows_device: copy of the root's own rows failed";
+                    rc = APR_ERR_DEVICE;
+                }
+                continue;
+            }
+            // rows travel as bytes: their exact bit patterns, whatever the element type
+            if (hipSetDevice(devs[i]) != hipSuccess) { rc = APR_ERR_DEVICE; break; }
+            r = api->Send(p.src[i], bytes, p.ty, root, comms[i], engines[i]->stream);
+            if (r != ncclSuccess) break;
+            if (hipSetDevice(devs[root]) != hipSuccess) { rc = APR_ERR_DEVICE; break; }
+            r = api->Recv(dst, bytes, p.ty, i, comms[root], er->stream);
+        }
+        const ncclResult_t r2 = api->GroupEnd();     // always closed, also after an error inside the group
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) { er->err = std::string("apr_gather_rows_device: RCCL: ") + api->GetErrorString(r); rc = APR_ERR_DEVICE; }
+        if (rc) break;
+    }
+    for (int i = 0; i < n_engines; i++) {
+        if (hipSetDevice(devs[i]) != hipSuccess || hipStreamSynchronize(engines[i]->stream) != hipSuccess) {
+            if (!rc) { er->err = "apr_gather_rows_device: stream synchronisation failed"; rc = APR_ERR_DEVICE; }
+        }
+    }
+    (void)hipSetDevice(devs[root]);
+    return rc;
 }
 
 size_t apr_windows_in(size_t nbytes, size_t stride_bytes)

@@ -92,6 +92,8 @@ def _addr(a) -> int:
     """address of a numpy array (host) or a torch tensor (host or device)"""
     if a is None:
         return 0
+    if isinstance(a, int):          # a raw device address (Engine.device_alloc)
+        return a
     if isinstance(a, np.ndarray):
         if not a.flags["C_CONTIGUOUS"]:
             raise ValueError("array must be C-contiguous")
@@ -282,6 +284,46 @@ class Engine:
         """apr_bucket_hits_device: one hit per class per minute from device-resident (label, match) rows."""
         self._chk(self._lib.apr_bucket_hits_device(self._h, _addr(d_label), _addr(d_match), n_windows, n_classes,
                                                    windows_per_bucket, _addr(d_hits)))
+
+    # ---- device memory for hosts without an allocator of their own (what the Go shim uses; torch tensors work as well) ----
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self._lib.apr_device_alloc(self._h, nbytes, C.byref(p)))
+        return p.value or 0
+
+    def device_free(self, d_ptr: int) -> None:
+        self._chk(self._lib.apr_device_free(self._h, d_ptr))
+
+    def device_upload(self, d_dst: int, host) -> None:
+        b = _as_u8(host)
+        self._chk(self._lib.apr_device_upload(self._h, d_dst, b.ctypes.data, b.size))
+
+    def device_download(self, d_src: int, out: np.ndarray) -> np.ndarray:
+        self._chk(self._lib.apr_device_download(self._h, out.ctypes.data, d_src, out.nbytes))
+        return out
+
+    @staticmethod
+    def gather_rows_device(engines, n_rows, n_classes: int, d_probs, d_label, d_match, d_probs_out, d_label_out, d_match_out,
+                           root: int = 0) -> None:
+        """apr_gather_rows_device: the final gather of a one-process multi-GPU sweep over RCCL (device pointers: ints or torch
+        tensors; a tensor that is not wanted is None in the per-engine list and in the output)."""
+        if not engines:
+            raise ValueError("gather_rows_device needs at least one engine")
+        n = len(engines)
+        lib = engines[0]._lib
+        hs = (C.c_void_p * n)(*[e._h.value for e in engines])
+        rows = (C.c_size_t * n)(*[int(r) for r in n_rows])
+
+        def ptrs(lst):
+            if lst is None:
+                return None
+            return (C.c_void_p * n)(*[_addr(t) for t in lst])
+        rc = lib.apr_gather_rows_device(hs, n, root, rows, n_classes, ptrs(d_probs), ptrs(d_label), ptrs(d_match),
+                                        _addr(d_probs_out), _addr(d_label_out), _addr(d_match_out))
+        if rc < 0:
+            # argument errors are kept per thread (apr_last_error(NULL)), later ones on the root engine
+            msg = (lib.apr_last_error(engines[root]._h) if 0 <= root < n else b"") or lib.apr_last_error(None) or b""
+            raise AprError(rc, msg.decode())
 
     def infer_device(self, d_spec, batch: int, d_logits) -> None:
         self._chk(self._lib.apr_infer_device(self._h, _addr(d_spec), batch, _addr(d_logits)))

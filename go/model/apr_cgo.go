@@ -7,7 +7,7 @@
 //     (model.go:188-229) and the go-dsp / onnx-go imports are removed; the constants,
 //     OnnxModel, Train, Load, softmax and normalizeAudio stay exactly as they are,
 //   * this file is added next to it and supplies Prepare, Infer and the new ScoreBatch,
-//     SweepFiles, WavDataOffset and BucketHits (go 1.24 in src/go.mod:3 has runtime.Pinner).
+//     SweepFiles, SweepFilesMulti, SweepFilesGatherHits, WavDataOffset and BucketHits (go 1.24 in src/go.mod:3 has runtime.Pinner).
 // The exported surface of the package is therefore unchanged; every number is computed
 // behind the C ABI except the f64 softmax + label map, which remain the reference's own.
 //
@@ -19,6 +19,8 @@ package model
 #cgo LDFLAGS: -L${SRCDIR}/../../apr_amd -lapr_amd
 #include <stdlib.h>
 #include "apr.h"
+// byte offset into device memory (a device address is not a Go pointer: the arithmetic stays in C)
+static inline void *apr_at(void *p, size_t off) { return (char *)p + off; }
 */
 import "C"
 
@@ -492,6 +494,162 @@ func SweepFilesMulti(inferModel OnnxModel, devices []int, files [][]byte, trust 
 	}
 	for f := range first {
 		first[f] = int(cfirst[f])
+	}
+	return
+}
+
+// SweepFilesGatherHits is the device-resident form of SweepFilesMulti, the shape north_star describes: recordings shard by file over
+// the listed GPUs (file f -> devices[f % len(devices)]), every GPU scores its shard with the rows left in its HBM
+// (apr_score_device), the rows are gathered on the first listed GPU over RCCL / xGMI (apr_gather_rows_device), the one-hit-per-
+// minute report (docs/usage/review.md:48-53) is formed there (apr_bucket_hits_device), and only that report crosses PCIe:
+// hits[f][b][c] is true iff class c matched at least once in minute b of recording f.  One process; one engine per device.
+func SweepFilesGatherHits(inferModel OnnxModel, devices []int, files [][]byte, trust float64) (hits [][][]bool) {
+	nf, nd := len(files), len(devices)
+	hits = make([][][]bool, nf)
+	if nf == 0 || nd == 0 {
+		return
+	}
+	seen := map[int]bool{}
+	for _, d := range devices {
+		if seen[d] {
+			log.Die("Inference failed: SweepFilesGatherHits: device %d listed twice", d)
+		}
+		seen[d] = true
+	}
+	empty := -1
+	for i, l := range inferModel.Labels {
+		if l == "empty" {
+			empty = i
+		}
+	}
+	es := make([]*engine, nd)
+	for i, d := range devices {
+		es[i] = cachedEngine(inferModel, batchWindows, d)
+	}
+	nc := es[0].nc
+	order := make([]int, nd)
+	for i := range order {
+		order[i] = i
+	}
+	sort.Slice(order, func(a, b int) bool { return devices[order[a]] < devices[order[b]] })
+	for _, i := range order {
+		es[i].mu.Lock()
+	}
+	defer func() {
+		for _, i := range order {
+			es[i].mu.Unlock()
+		}
+	}()
+	// the shard plan: windows of every file, rows of every device, each file's first row in gather (= device, then file) order
+	wins := make([]int, nf)
+	rows := make([]int, nd)
+	for f, b := range files {
+		wins[f] = int(C.apr_windows_in(C.size_t(len(b)), C.size_t(ffmpeg.BytesPerSecond)))
+		rows[f%nd] += wins[f]
+	}
+	base := make([]int, nd+1)
+	for d := 0; d < nd; d++ {
+		base[d+1] = base[d] + rows[d]
+	}
+	total := base[nd]
+	if total == 0 {
+		return
+	}
+	chk := func(e *engine, rc C.int) {
+		if rc != 0 {
+			log.Die("Inference failed: %v", lastErr(e.h))
+		}
+	}
+	alloc := func(e *engine, n int) unsafe.Pointer {
+		var p unsafe.Pointer
+		chk(e, C.apr_device_alloc(e.h, C.size_t(n), &p))
+		return p
+	}
+	cEng := (*[1 << 16]*C.apr_engine)(C.malloc(C.size_t(nd) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:nd:nd]
+	cRows := (*[1 << 16]C.size_t)(C.malloc(C.size_t(nd) * C.size_t(unsafe.Sizeof(C.size_t(0)))))[:nd:nd]
+	cLab := (*[1 << 16]*C.int32_t)(C.malloc(C.size_t(nd) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:nd:nd]
+	cMat := (*[1 << 16]*C.uint8_t)(C.malloc(C.size_t(nd) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:nd:nd]
+	defer C.free(unsafe.Pointer(&cEng[0]))
+	defer C.free(unsafe.Pointer(&cRows[0]))
+	defer C.free(unsafe.Pointer(&cLab[0]))
+	defer C.free(unsafe.Pointer(&cMat[0]))
+	firstRow := make([]int, nf) // row of file f's first window in gather order
+	var owned []struct {
+		e *engine
+		p unsafe.Pointer
+	}
+	defer func() {
+		for _, o := range owned {
+			C.apr_device_free(o.e.h, o.p)
+		}
+	}()
+	keep := func(e *engine, p unsafe.Pointer) unsafe.Pointer {
+		owned = append(owned, struct {
+			e *engine
+			p unsafe.Pointer
+		}{e, p})
+		return p
+	}
+	for d := 0; d < nd; d++ {
+		e := es[d]
+		cEng[d], cRows[d] = e.h, C.size_t(rows[d])
+		dLab := keep(e, alloc(e, 4*rows[d]+4))
+		dMat := keep(e, alloc(e, rows[d]+4))
+		cLab[d], cMat[d] = (*C.int32_t)(dLab), (*C.uint8_t)(dMat)
+		done := 0
+		for f := d; f < nf; f += nd { // this device's recordings, in file order: no window crosses a recording
+			firstRow[f] = base[d] + done
+			if wins[f] == 0 {
+				continue
+			}
+			dPcm := alloc(e, len(files[f]))
+			chk(e, C.apr_device_upload(e.h, dPcm, unsafe.Pointer(&files[f][0]), C.size_t(len(files[f]))))
+			rc := C.apr_score_device(e.h, (*C.uint8_t)(dPcm), C.size_t(len(files[f])), C.size_t(wins[f]), C.size_t(ffmpeg.BytesPerSecond),
+				C.double(trust), C.int(empty), nil, (*C.int32_t)(C.apr_at(dLab, C.size_t(4*done))), (*C.uint8_t)(C.apr_at(dMat, C.size_t(done))), nil)
+			if rc == 0 {
+				rc = C.apr_sync(e.h) // the PCM buffer is freed next
+			}
+			C.apr_device_free(e.h, dPcm)
+			chk(e, rc)
+			done += wins[f]
+		}
+	}
+	root := es[0]
+	gLab := keep(root, alloc(root, 4*total))
+	gMat := keep(root, alloc(root, total))
+	if rc := C.apr_gather_rows_device(&cEng[0], C.int(nd), 0, &cRows[0], C.int(nc), nil, &cLab[0], &cMat[0], nil, (*C.int32_t)(gLab), (*C.uint8_t)(gMat)); rc != 0 {
+		log.Die("Inference failed: %v", lastErr(root.h))
+	}
+	// one report per recording, formed on the root GPU from the gathered rows
+	const wpb = 60
+	nbTotal := 0
+	nbOf := make([]int, nf)
+	for f := range files {
+		nbOf[f] = (wins[f] + wpb - 1) / wpb
+		nbTotal += nbOf[f]
+	}
+	dHits := keep(root, alloc(root, nbTotal*nc+4))
+	off := 0
+	for f := range files {
+		if wins[f] > 0 {
+			chk(root, C.apr_bucket_hits_device(root.h, (*C.int32_t)(C.apr_at(gLab, C.size_t(4*firstRow[f]))), (*C.uint8_t)(C.apr_at(gMat, C.size_t(firstRow[f]))),
+				C.size_t(wins[f]), C.int(nc), wpb, (*C.uint8_t)(C.apr_at(dHits, C.size_t(off*nc)))))
+		}
+		off += nbOf[f]
+	}
+	flat := make([]uint8, nbTotal*nc+1)
+	chk(root, C.apr_sync(root.h))
+	chk(root, C.apr_device_download(root.h, unsafe.Pointer(&flat[0]), dHits, C.size_t(nbTotal*nc)))
+	off = 0
+	for f := range files {
+		hits[f] = make([][]bool, nbOf[f])
+		for b := range hits[f] {
+			hits[f][b] = make([]bool, nc)
+			for c := 0; c < nc; c++ {
+				hits[f][b][c] = flat[(off+b)*nc+c] != 0
+			}
+		}
+		off += nbOf[f]
 	}
 	return
 }

@@ -329,6 +329,34 @@ int apr_profile_reset(apr_engine *e);
 int apr_profile_read(apr_engine *e, apr_profile_slot *slots /*[APR_PROF_SLOTS]*/, int *n_slots);
 
 /*
+ * Device memory for hosts that have no allocator of their own (the Go shim; a Python host uses torch tensors): plain
+ * hipMalloc / hipFree / hipMemcpy on the engine's GPU, so that a cgo caller can keep PCM and score rows device-resident between
+ * apr_score_device, apr_gather_rows_device and apr_bucket_hits_device.  No counterpart in the reference (its path is CPU-only).
+ * apr_device_upload / _download are synchronous on the engine's stream (they return when the copy is done).
+ */
+int apr_device_alloc(apr_engine *e, size_t nbytes, void **d_out);
+int apr_device_free(apr_engine *e, void *d_ptr);
+int apr_device_upload(apr_engine *e, void *d_dst, const void *h_src, size_t nbytes);
+int apr_device_download(apr_engine *e, void *h_dst, const void *d_src, size_t nbytes);
+
+/*
+ * The final gather of a multi-GPU sweep for a ONE-process host (north_star: recordings shard by file over the GPUs of a node,
+ * "RCCL over xGMI used only for the final gather of per-clip scores").  engines[i] is the engine of GPU i (all
+ * distinct devices), n_rows[i] the windows it scored, d_probs[i] / d_label[i] / d_match[i] its device-resident rows as
+ * apr_score_device wrote them ([n_rows[i]][n_classes] f64, i32, u8; a tensor that is not wanted is NULL for every engine and in
+ * the outputs).  The rows of engine i land at row offset n_rows[0] + .. + n_rows[i-1] of the *_out buffers on the GPU of
+ * engines[root]: engine order = the shard order of apr_sweep_plan.  Every sender uses its own point-to-point link to the root
+ * (ncclSend / ncclRecv in one group -- a flat gather, not a ring: SURVEY 5), the root's own rows are a device-to-device copy.
+ * The call returns when every stream involved has finished.  librccl is loaded on first use (dlopen "librccl.so.1"), the
+ * communicator of a device list is created once per process (ncclCommInitAll) and kept.  The reference has no counterpart
+ * (single process, CPU); the one-process-per-GPU form of the same gather is apr_amd/sweep.py: gather_scores (torch.distributed).
+ * Measured on hardware with one GPU only (tests/test_gpu_configs.py); N > 1 is by construction.
+ */
+int apr_gather_rows_device(apr_engine *const *engines, int n_engines, int root, const size_t *n_rows, int n_classes,
+                           const double *const *d_probs, const int32_t *const *d_label, const uint8_t *const *d_match,
+                           double *d_probs_out, int32_t *d_label_out, uint8_t *d_match_out);
+
+/*
  * Deterministic synthetic PCM (host side, no GPU): SURVEY 8(d) recipe.  A 16 kHz
  * signal (noise at -30 dBFS, 0-3 Hann-shaped tone/chirp bursts per second,
  * exact-zero stretches) interpolated x3 to 48 kHz, s16 saturated.  file seed =

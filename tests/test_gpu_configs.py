@@ -214,3 +214,44 @@ def test_bucket_hits_on_the_gpu_equals_the_host_form(he_weights):
     assert np.array_equal(d_hits.cpu().numpy(), sweep.bucket_hits(d_label.cpu().numpy(), d_match.cpu().numpy(), 4))
     assert d_match.sum().item() > 0
     fe.close(); eng.close()
+
+
+def test_device_resident_sweep_gather_and_hits(he_weights):
+    # The device-resident end of a one-process multi-GPU sweep, as a Go host would drive it through the C ABI alone: PCM uploaded into
+    # memory from apr_device_alloc, apr_score_device, apr_gather_rows_device (RCCL communicator over the device list; this box has one GPU,
+    # so the root's own rows are what moves), apr_bucket_hits_device on the gathered rows, and only the hits downloaded.
+    eng = model.Engine(W.pack_blob(he_weights, 4), 0, 64)
+    pcm = model.synth_pcm(11, 3, 150).view(np.uint8)
+    n = model.windows_in(pcm.size)
+    want = eng.score(pcm, n, trust=0.3, empty_class=EMPTY)
+    d_pcm = eng.device_alloc(pcm.size)
+    d_probs, d_label, d_match = eng.device_alloc(n * 4 * 8), eng.device_alloc(n * 4), eng.device_alloc(n)
+    g_probs, g_label, g_match = eng.device_alloc(n * 4 * 8), eng.device_alloc(n * 4), eng.device_alloc(n)
+    nb = (n + 59) // 60
+    d_hits = eng.device_alloc(nb * 4)
+    assert d_pcm and d_probs and g_match and d_hits
+    eng.device_upload(d_pcm, pcm)
+    eng.score_device(d_pcm, pcm.size, n, 96000, 0.3, EMPTY, d_probs, d_label, d_match)
+    model.Engine.gather_rows_device([eng], [n], 4, [d_probs], [d_label], [d_match], g_probs, g_label, g_match, root=0)
+    probs = eng.device_download(g_probs, np.empty((n, 4), np.float64))
+    label = eng.device_download(g_label, np.empty(n, np.int32))
+    match = eng.device_download(g_match, np.empty(n, np.uint8))
+    assert np.array_equal(probs, want["probs"]) and np.array_equal(label, want["label"]) and np.array_equal(match, want["match"])
+    eng.bucket_hits_device(g_label, g_match, n, 4, d_hits)
+    hits = eng.device_download(d_hits, np.empty((nb, 4), np.uint8))
+    assert np.array_equal(hits, sweep.bucket_hits(want["label"], want["match"], 4)) and hits.any()
+    # only labels wanted: the other tensors stay NULL; a second call reuses the communicator
+    model.Engine.gather_rows_device([eng], [n], 4, None, [d_label], None, None, g_label, None)
+    # an output without its inputs, and a root that does not exist, are errors
+    with pytest.raises(AprError):
+        model.Engine.gather_rows_device([eng], [n], 4, None, [d_label], None, g_probs, g_label, None)
+    with pytest.raises(AprError):
+        model.Engine.gather_rows_device([eng], [n], 4, None, [d_label], None, None, g_label, None, root=1)
+    e2 = model.Engine(None, 0, 8)
+    with pytest.raises(AprError) as ei:           # two engines on one device: one rank per GPU
+        model.Engine.gather_rows_device([eng, e2], [n, 0], 4, None, [d_label, None], None, None, g_label, None)
+    assert "one device" in str(ei.value)
+    e2.close()
+    for p in (d_pcm, d_probs, d_label, d_match, g_probs, g_label, g_match, d_hits):
+        eng.device_free(p)
+    eng.close()

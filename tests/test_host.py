@@ -358,6 +358,22 @@ def test_sweep_plan_round_robin_by_file():
         model.sweep_plan([96000], 0)
 
 
+def test_gather_rows_device_rejects_bad_arguments_without_a_gpu():
+    # apr_gather_rows_device validates before it touches RCCL or a device: error codes, never a crash
+    import ctypes as C
+    L = _capi.lib()
+    rows = (C.c_size_t * 1)(3)
+    null_engines = (C.c_void_p * 1)(None)
+    assert L.apr_gather_rows_device(None, 1, 0, rows, 4, None, None, None, None, None, None) == _capi.ERR_INVALID
+    assert L.apr_gather_rows_device(null_engines, 0, 0, rows, 4, None, None, None, None, None, None) == _capi.ERR_INVALID
+    assert L.apr_gather_rows_device(null_engines, 1, 1, rows, 4, None, None, None, None, None, None) == _capi.ERR_INVALID      # root out of range
+    assert L.apr_gather_rows_device(null_engines, 1, 0, rows, 65, None, None, None, None, None, None) == _capi.ERR_INVALID     # classes
+    assert L.apr_gather_rows_device(null_engines, 1, 0, rows, 4, None, None, None, None, None, None) == _capi.ERR_INVALID      # null engine
+    assert b"apr_gather_rows_device" in L.apr_last_error(None)
+    p = C.c_void_p()
+    assert L.apr_device_alloc(None, 16, C.byref(p)) == _capi.ERR_INVALID and L.apr_device_free(None, None) == _capi.ERR_INVALID
+
+
 def test_header_is_plain_c99_and_callable_from_c(tmp_path):
     # cgo consumes include/apr.h as C: compile it as C99 and drive the host-only entry points from a C program
     import shutil
