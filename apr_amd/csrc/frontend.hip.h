@@ -255,6 +255,9 @@ __global__ __launch_bounds__(64 * kFramesPerBlock) __attribute__((amdgpu_waves_p
         float accA = 0.0f, accB = 0.0f;
         const float4 *P4 = reinterpret_cast<const float4 *>(pl);
         const float4 *W4 = reinterpret_cast<const float4 *>(s_w);
+#ifdef APR_FE_ABL_NOMEL   // developer timing ablation (wrong results): what the mel projection costs inside the kernel
+        if (pl[lane] == 12345.678f)
+#endif
         for (int i = 0; i < maxq; i++) {
             if (i < qnA) {
                 const float4 p = P4[qsA + i], w = W4[qoA + i];
