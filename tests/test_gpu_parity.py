@@ -12,8 +12,10 @@ from conftest import GOLDEN, LABELS
 
 pytestmark = pytest.mark.gpu
 
-# fp32 front end vs the f64 reference restatement: spectrogram values live in [0,1]
-SPEC_TOL = 2e-5
+# fp32 front end vs the f64 reference restatement: spectrogram values live in [0,1].  The fp32 FFT's rounding noise (~1e-7 of a frame's
+# largest amplitude) is a visible fraction of the bins 60-80 dB below the window's maximum: measured <= 1e-6 on the reference's four
+# clips, 1.6e-5 typical and 2.8e-5 worst over the 5 990 synthetic windows of tools/parity_soak.py (profiles/r03_parity_soak.json)
+SPEC_TOL = 5e-5
 # fp32 CNN, different summation order (K up to 9216): logits are O(1)
 LOGIT_TOL = 2e-4
 
