@@ -2042,6 +2042,15 @@ int apr_profile_read(apr_engine *e, apr_profile_slot *slots, int *n_slots)
 
 }  // extern "C"
 
+#ifdef W4_STAMPS   // developer build (tools/w4_stamps.py)
+extern "C" int apr_debug_w4_stamps(unsigned long long *dst, int reset)
+{
+    static const unsigned long long zero[64] = {};
+    if (reset) return hipMemcpyToSymbol(HIP_SYMBOL(apr::w4_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(apr::w4_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 #if defined(WS_STAMPS) || defined(W8_STAMPS)   // developer builds (tools/ws_stamps.py): 64 counters of workgroup 0 of the stamped kernel
 extern "C" int apr_debug_ws_stamps(unsigned long long *dst, int reset)
 {

@@ -32,6 +32,14 @@ namespace apr {
 #define W4_ABL 0   // developer timing ablations (wrong results): 1 no slab DMA after a unit's first, 2 no exchange through X, 4 no output stores, 8 no transform arithmetic
 #endif
 
+#ifdef W4_STAMPS   // developer build (tools/w4_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles in the MFMA part of the K steps [0], in their
+                   // closing wait + barrier [1], in the pass ends (exchange + transform) [2], between two units' K loops (stores, set-up) [3]; steps [4], passes [5], units [6]
+__device__ unsigned long long w4_stamps[8][8];
+#define W4_ST(I_) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); st4[I_] += t_ - stt; stt = t_; }
+#else
+#define W4_ST(I_)
+#endif
+
 constexpr int W4_TT = 64;                        // tiles per unit
 constexpr int W4_BN = 64;                        // output channels per unit
 constexpr int W4_BK = 16;                        // input channels per K step
@@ -198,6 +206,10 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
     W4_DMA(rsV, rsU, 1, 1)
     int tb = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef W4_STAMPS
+    unsigned st4[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned stt = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
 
     for (;;) {
         const int nl = lidl + per;
@@ -231,6 +243,7 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
             for (int e = 0; e < 8; e++) y[p][e] = 0.0f;
         __syncthreads();                                // step 0 of this unit is in slot 0 (every wave waited for its own pieces)
 
+        W4_ST(3)
         int s = 0, slot = 0;
         for (int i = 0; i < 6; i++) {
             f32x16 acc[3];
@@ -267,6 +280,7 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                W4_ST(0)
                 if (kc == KC - 1) {
                     // ---- the pass's M: MFMA layout -> transform layout through X = the slot this step read, three positions at a time ----
                     float *X = w4_smem + slot * W4_SLOT;
@@ -336,11 +350,16 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+#ifdef W4_STAMPS
+                if (kc == KC - 1) { W4_ST(2) st4[5]++; }
+                st4[4]++;
+#endif
                 // the next step's slabs have landed (the six DMAs issued at the top of this step may still be in flight).  Step 0 of a unit
                 // waits for everything: the unit before it has just issued its output stores, and loads and stores do not retire in one order
                 if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 __syncthreads();
+                W4_ST(1)
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
@@ -356,10 +375,18 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                 if (!(W4_ABL & 4) || y[p][e] == 12345.678f) wf_store1(rsO, o, wf_relu(y[p][e] + bv));
             }
         }
+#ifdef W4_STAMPS
+        st4[6]++;
+#endif
         if (!more) break;
         bm = bm_n; bn = bn_n; tb ^= 1; lidl = nl;
         rsV.x = rsVn.x; rsV.y = rsVn.y; rsU.x = rsUn.x; rsU.y = rsUn.y;
     }
+#ifdef W4_STAMPS
+    W4_ST(3)
+    if (blockIdx.x == 0 && lane == 0)
+        for (int q = 0; q < 8; q++) w4_stamps[wave][q] += st4[q];
+#endif
 #undef W4_DESC
 #undef W4_DMA
 #undef W4_DMA1
