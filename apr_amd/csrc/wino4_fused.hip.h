@@ -9,9 +9,9 @@
 // Why not 36 positions side by side: 36 x (64 tiles x 64 channels) accumulators are 2.25x the register file.  The output
 // transform is linear in the positions, so the unit is computed in SIX PASSES, one row i of the 6x6 positions each:
 // 6 position GEMMs (24 streams of 32x32 blocks over 8 waves: 48 accumulator registers a wave), then the pass's M goes through
-// LDS from the MFMA layout (wave = block x 3 positions) to the transform layout (wave = 8 tiles, lane = channel, all six
+// LDS from the MFMA layout (wave = block x 3 positions) to the transform layout (wave = 8 tiles, lane = 4 channels x 2 tiles, all six
 // positions), where R[b] = sum_j A^T[b][j] M[i][j] and Y[a][b] += A^T[a][i] R[b] accumulate the unit's 16 outputs per
-// (tile, channel) in registers (128 a lane).  After pass 5: + bias, ReLU, one 256-B run per pixel and store instruction.
+// (tile, channel) in registers (128 a lane).  After pass 5: + bias, ReLU, 16-B stores (a lane = four channels of two tiles).
 //
 // Work unit = 64 tiles (1024 output pixels) x 64 channels, one persistent workgroup of 8 waves per CU (wf8_grid, wf_unit order).
 // K step = 16 input channels = one slab each of V and U: [sub 2][j 6][row 64][8 floats] = 24 KiB, host- / producer-packed in
@@ -130,10 +130,10 @@ struct W4Args {
     int n_units;
 };
 
-// exchange buffer X[3 positions][64 channels][16 quads of tiles][4]: the 16-B quad index is XOR-ed with the channel's low four bits, so
-// both the MFMA-side ds_write_b128 (a lane = a channel, four consecutive tile rows) and the transform-side ds_read_b128 (a lane =
-// a channel, a wave's eight tiles) spread eight consecutive lanes over all banks
-__device__ __forceinline__ int w4_x_index(int jj, int ch, int tile_quad) { return ((jj * 64 + ch) * 16 + (tile_quad ^ (ch & 15))) * 4; }
+// exchange buffer X[3 positions][64 channels][16 quads of tiles][4]: the 16-B quad index is XOR-ed with bits of the channel (ch ^ ch >> 2), so
+// both the MFMA-side ds_write_b128 (a lane = a channel, four consecutive tile rows) and the transform-side ds_read_b64 (a lane =
+// four consecutive channels x two tiles: sixteen lanes = sixteen channel groups of one tile pair) spread the lanes of a cycle over all banks
+__device__ __forceinline__ int w4_x_index(int jj, int ch, int tile_quad) { return ((jj * 64 + ch) * 16 + (tile_quad ^ ((ch ^ (ch >> 2)) & 15))) * 4; }
 
 __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
 {
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
             tbl[tb * 128 + 2 * tid] = off;
             tbl[tb * 128 + 2 * tid + 1] = mask;
         }
-        const int n = bn * W4_BN + lane;                // the lane's output channel in the transform layout
-        const float bv = a.bias[n];
+        const int n = bn * W4_BN + 4 * (lane & 15);     // the lane's four output channels in the transform layout
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + n);
         float y[16][8];
 #pragma unroll
         for (int p = 0; p < 16; p++)
@@ -305,33 +305,36 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                     if (!(W4_ABL & 2)) __syncthreads();  // every wave is done reading the slot
                     if (jh == 0 && !(W4_ABL & 2)) { W4_X_WRITE() }
                     if (!(W4_ABL & 2)) __syncthreads();
-                    // positions 0..2 of this wave's 8 tiles, folded at once: p0 = m0 + (m1 + m2), sp = m1 + m2, dp = m1 - m2
+                    // transform layout: lane = (channel group cg of four channels, tile pair tp of the wave's eight tiles); element e = 2 c + t
+                    const int cgx = lx & 15, tpx = lx >> 4;
+                    const int xq = 2 * wave + (tpx >> 1), xo = 2 * (tpx & 1);
+                    // positions 0..2, folded at once: p0 = m0 + (m1 + m2), sp = m1 + m2, dp = m1 - m2
                     float p0[8], sp[8], dp[8];
 #pragma unroll
-                    for (int q2 = 0; q2 < 2; q2++) {
-                        const f32x4 m0 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(0, lx, 2 * wave + q2));
-                        const f32x4 m1 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(1, lx, 2 * wave + q2));
-                        const f32x4 m2 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(2, lx, 2 * wave + q2));
+                    for (int c = 0; c < 4; c++) {
+                        const f32x2 m0 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(0, 4 * cgx + c, xq) + xo);
+                        const f32x2 m1 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(1, 4 * cgx + c, xq) + xo);
+                        const f32x2 m2 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(2, 4 * cgx + c, xq) + xo);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            sp[4 * q2 + k] = m1[k] + m2[k];
-                            dp[4 * q2 + k] = m1[k] - m2[k];
-                            p0[4 * q2 + k] = m0[k] + sp[4 * q2 + k];
+                        for (int k = 0; k < 2; k++) {
+                            sp[2 * c + k] = m1[k] + m2[k];
+                            dp[2 * c + k] = m1[k] - m2[k];
+                            p0[2 * c + k] = m0[k] + sp[2 * c + k];
                         }
                     }
                     if (!(W4_ABL & 2)) __syncthreads();
                     if (jh == 1 && !(W4_ABL & 2)) { W4_X_WRITE() }
                     if (!(W4_ABL & 2)) __syncthreads();
 #undef W4_X_WRITE
-                    // positions 3..5, four tiles at a time: R[b] = sum_j A^T[b][j] M[i][j], then Y[a][b] += A^T[a][i] R[b]
+                    // positions 3..5, a channel (two tiles) at a time: R[b] = sum_j A^T[b][j] M[i][j], then Y[a][b] += A^T[a][i] R[b]
 #pragma unroll
-                    for (int q2 = 0; q2 < 2; q2++) {
-                        const f32x4 m3 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(0, lx, 2 * wave + q2));
-                        const f32x4 m4 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(1, lx, 2 * wave + q2));
-                        const f32x4 m5 = *reinterpret_cast<const f32x4 *>(X + w4_x_index(2, lx, 2 * wave + q2));
+                    for (int c = 0; c < 4; c++) {
+                        const f32x2 m3 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(0, 4 * cgx + c, xq) + xo);
+                        const f32x2 m4 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(1, 4 * cgx + c, xq) + xo);
+                        const f32x2 m5 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(2, 4 * cgx + c, xq) + xo);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int e = 4 * q2 + k;
+                        for (int k = 0; k < 2; k++) {
+                            const int e = 2 * c + k;
                             const float sq = m3[k] + m4[k], dq = m3[k] - m4[k];
                             float R[4];
                             R[0] = p0[e] + sq;
@@ -363,16 +366,21 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
-        // ---- + bias, ReLU, store: lane = channel, so every store instruction writes one pixel's 64 channels (256 B) ----
+        // ---- + bias, ReLU, store: a lane holds four consecutive channels of two tiles, so every store instruction writes 16 B a lane: sixteen lanes =
+        //      one pixel's 64 channels (256 B), 32 store instructions a lane and unit (one channel a lane: 128, and 8 k cycles between two units' K loops) ----
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
         const unsigned nb4 = 4u * (unsigned)n;
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const unsigned off = tbl[tb * 128 + 2 * (8 * wave + e)], mask = tbl[tb * 128 + 2 * (8 * wave + e) + 1];
+        for (int t = 0; t < 2; t++) {
+            const int tile = 8 * wave + 2 * (lane >> 4) + t;
+            const unsigned off = tbl[tb * 128 + 2 * tile], mask = tbl[tb * 128 + 2 * tile + 1];
 #pragma unroll
             for (int p = 0; p < 16; p++) {
                 const unsigned o = ((mask >> p) & 1u) ? off + 4u * (unsigned)(((p >> 2) * W + (p & 3)) * Cout) + nb4 : OOB;
-                if (!(W4_ABL & 4) || y[p][e] == 12345.678f) wf_store1(rsO, o, wf_relu(y[p][e] + bv));
+                u32x4 v;
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = __builtin_bit_cast(unsigned, wf_relu(y[p][2 * c + t] + bv[c]));
+                if (!(W4_ABL & 4) || y[p][t] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(v, rsO, o, 0, APR_WF_STORE_AUX);
             }
         }
 #ifdef W4_STAMPS
