@@ -762,8 +762,10 @@ int run_cnn(apr_engine *e, const float *d_spec, int batch, double trust, int emp
             {
                 const long long n_blocks = ((T + W4_TT - 1) / W4_TT) * (L.cin / W4_BK);      // < 2^31: max_batch is capped at create
                 ProfScope ps(e, L.slot_in, 0.0, 4.0 * ((double)batch * L.hin * L.win * L.cin + 36.0 * T * L.cin));
-                hipLaunchKernelGGL(wino_input_f4p, dim3((unsigned)n_blocks), dim3(256), 0, e->stream, in,
-                                   e->d_V, L.hin, L.win, L.cin, L.th, L.tw, T, (int)n_blocks);
+                if (36.0 * 4.0 * (double)T * L.cin > 2.0e9)
+                    hipLaunchKernelGGL(wino_input_f4p<true>, dim3((unsigned)n_blocks), dim3(256), 0, e->stream, in, e->d_V, L.hin, L.win, L.cin, L.th, L.tw, T, (int)n_blocks);
+                else
+                    hipLaunchKernelGGL(wino_input_f4p<false>, dim3((unsigned)n_blocks), dim3(256), 0, e->stream, in, e->d_V, L.hin, L.win, L.cin, L.th, L.tw, T, (int)n_blocks);
             }
             {
                 const int tiles_n = L.cout / W4_BN;

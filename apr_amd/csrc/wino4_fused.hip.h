@@ -79,6 +79,7 @@ inline void w4_pack_u(const float *w, int cin, int cout, float *up)
 // sub 0 and of sub 1).  Workgroups of one unit (kc = 0 .. KC-1) follow each other inside an XCD's contiguous run, so the 128-B lines
 // of a pixel that the KC workgroups share are fetched into one L2.
 // Rows of the last unit past T are never written: their products land in output rows that are never stored.
+template <bool NT>   // NT: streaming stores (two instantiations: under a run-time branch hipcc merges the two stores and drops the hint)
 __global__ __launch_bounds__(256) void wino_input_f4p(const float *__restrict__ in, float *__restrict__ Vp, int H, int W, int C, int th, int tw,
                                                       long long T, int n_blocks)
 {
@@ -118,7 +119,12 @@ __global__ __launch_bounds__(256) void wino_input_f4p(const float *__restrict__ 
         f32x4 v[6];
         wino4_bt(tmp[i][0], tmp[i][1], tmp[i][2], tmp[i][3], tmp[i][4], tmp[i][5], v[0], v[1], v[2], v[3], v[4], v[5]);
 #pragma unroll
-        for (int j = 0; j < 6; j++) st4(o0 + i * pass_stride + j * 512, v[j]);
+        for (int j = 0; j < 6; j++) {
+            // a V far larger than the Infinity Cache is read once, by another kernel, long after: streaming stores keep it out of the caches the
+            // patches' halo reads live in (layer 3 at 4096 windows: 4.31 -> 3.94 ms; a V of 0.6 GB is better left cached: 0.14 vs 0.16 ms)
+            if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<f32x4 *>(o0 + i * pass_stride + j * 512));
+            else st4(o0 + i * pass_stride + j * 512, v[j]);
+        }
     }
 }
 
