@@ -32,6 +32,10 @@ namespace apr {
 #define W4_ABL 0   // developer timing ablations (wrong results): 1 no slab DMA after a unit's first, 2 no exchange through X, 4 no output stores, 8 no transform arithmetic
 #endif
 
+#ifndef W4_UNROLL
+#define W4_UNROLL 1   // the six passes as straight-line code: the column of A^T is then a set of constants (a third of the Y update is a multiplication by 0)
+#endif
+
 #ifdef W4_STAMPS   // developer build (tools/w4_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles in the MFMA part of the K steps [0], in their
                    // closing wait + barrier [1], in the pass ends (exchange + transform) [2], between two units' K loops (stores, set-up) [3]; steps [4], passes [5], units [6]
 __device__ unsigned long long w4_stamps[8][8];
@@ -141,6 +145,8 @@ struct W4Args {
 // four consecutive channels x two tiles: sixteen lanes = sixteen channel groups of one tile pair) spread the lanes of a cycle over all banks
 __device__ __forceinline__ int w4_x_index(int jj, int ch, int tile_quad) { return ((jj * 64 + ch) * 16 + (tile_quad ^ ((ch ^ (ch >> 2)) & 15))) * 4; }
 
+__device__ __forceinline__ f32x2 w4_fma2(float c, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{c, c}, a, b); }
+
 __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float w4_smem[];      // [3 slots][V slab, U slab]; a consumed slot doubles as the exchange buffer
@@ -201,9 +207,11 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
             lds_dma_b128(RU_, dvoff, __builtin_amdgcn_readfirstlane((STEP_) * (W4_SLAB * 4) + pc_),      \
                          __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((SLOT_) * W4_SLOT + W4_SLAB) * 4 + pc_))); \
     }
-    const int rd_sw = (half ^ ((li >> 4) & 1)) * 4;
-    const int rd_a = (3 * jh) * 512 + (wm * 32 + li) * 8 + rd_sw;          // floats into a slot: this wave's first position, its lane's row of V
-    const int rd_b = W4_SLAB + (3 * jh) * 512 + (wn * 32 + li) * 8 + rd_sw; // ... of U
+    // floats into a slot: this wave's first position, its lane's row of V (the jh = 1 waves take rows 16..31 of their block first: the pass ends
+    // below) and of U
+    const int lr = li ^ (jh << 4);
+    const int rd_a = (3 * jh) * 512 + (wm * 32 + lr) * 8 + (half ^ ((lr >> 4) & 1)) * 4;
+    const int rd_b = W4_SLAB + (3 * jh) * 512 + (wn * 32 + li) * 8 + (half ^ ((li >> 4) & 1)) * 4;
 
     int bm, bn;
     wf_unit(x_start + lidl, a.mg, bm, bn);
@@ -240,17 +248,20 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
             tbl[tb * 128 + 2 * tid] = off;
             tbl[tb * 128 + 2 * tid + 1] = mask;
         }
-        const int n = bn * W4_BN + 4 * (lane & 15);     // the lane's four output channels in the transform layout
-        const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + n);
-        float y[16][8];
+        const int n = bn * W4_BN + wn * 32 + li;        // the lane's output channel: the transform works in the MFMA layout
+        const float bv = a.bias[n];
+        f32x2 y[16][4];                                 // the unit's 16 outputs of the lane's 8 tiles, starting from the bias
 #pragma unroll
         for (int p = 0; p < 16; p++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) y[p][e] = 0.0f;
+            for (int e = 0; e < 4; e++) y[p][e] = f32x2{bv, bv};
         __syncthreads();                                // step 0 of this unit is in slot 0 (every wave waited for its own pieces)
 
         W4_ST(3)
         int s = 0, slot = 0;
+#if W4_UNROLL
+#pragma unroll
+#endif
         for (int i = 0; i < 6; i++) {
             f32x16 acc[3];
             for (int kc = 0; kc < KC; kc++, s++) {
@@ -288,76 +299,76 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                 }
                 W4_ST(0)
                 if (kc == KC - 1) {
-                    // ---- the pass's M: MFMA layout -> transform layout through X = the slot this step read, three positions at a time ----
+                    // ---- the pass's M between the two waves of a block: wave (blk, jh) holds positions 3 jh .. 3 jh + 2 of all 32 tiles of its block, the
+                    //      transform wants all six positions of a tile in one lane.  Each wave keeps accumulator registers 0..7 (16 tiles: the A rows of
+                    //      the jh = 1 waves are taken with bit 4 flipped, so that these are tiles 0..15 for jh = 0 and 16..31 for jh = 1) and hands registers
+                    //      8..15 to its partner through X = the slot this step read, [wave][6][lane] x 16 B: lane-linear both ways, no bank conflicts ----
                     float *X = w4_smem + slot * W4_SLOT;
-                    // the lane's exchange addresses, from scratch: computed once per kernel they are kept in (and spilled from) registers
-                    // across the K loops
                     int lx = lane;
-                    asm volatile("" : "+v"(lx));
-                    const int lix = lx & 31, halfx = lx >> 5;
+                    asm volatile("" : "+v"(lx));            // the lane's exchange addresses from scratch: kept across the K loops they are spilled
+                    float *xw = X + (wave * 6 * 64 + lx) * 4;
+                    const float *xr = X + ((wave ^ 4) * 6 * 64 + lx) * 4;
                     // column i of A^T as scalars (rows 0 and 5 of M reach one output row each: the multiplications by 0 are kept, the
                     // code is one straight line for every pass).  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
                     const float c0 = i < 5 ? 1.0f : 0.0f;
                     const float c1 = (i == 1) ? 1.0f : (i == 2) ? -1.0f : (i == 3) ? 2.0f : (i == 4) ? -2.0f : 0.0f;
                     const float c2 = (i == 1 || i == 2) ? 1.0f : (i == 3 || i == 4) ? 4.0f : 0.0f;
                     const float c3 = (i == 1) ? 1.0f : (i == 2) ? -1.0f : (i == 3) ? 8.0f : (i == 4) ? -8.0f : (i == 5) ? 1.0f : 0.0f;
-#define W4_X_WRITE()                                                                                     \
-    _Pragma("unroll") for (int jj = 0; jj < 3; jj++)                                                     \
-        _Pragma("unroll") for (int e4 = 0; e4 < 4; e4++)                                                 \
-        {   /* accumulator registers 4 e4 .. 4 e4 + 3 = tile rows 8 e4 + 4 half + 0..3 of the block */   \
-            const f32x4 v_ = {acc[jj][4 * e4], acc[jj][4 * e4 + 1], acc[jj][4 * e4 + 2], acc[jj][4 * e4 + 3]}; \
-            *reinterpret_cast<f32x4 *>(X + w4_x_index(jj, wn * 32 + lix, wm * 8 + 2 * e4 + halfx)) = v_;   \
-        }
-                    if (!(W4_ABL & 2)) __syncthreads();  // every wave is done reading the slot
-                    if (jh == 0 && !(W4_ABL & 2)) { W4_X_WRITE() }
-                    if (!(W4_ABL & 2)) __syncthreads();
-                    // transform layout: lane = (channel group cg of four channels, tile pair tp of the wave's eight tiles); element e = 2 c + t
-                    const int cgx = lx & 15, tpx = lx >> 4;
-                    const int xq = 2 * wave + (tpx >> 1), xo = 2 * (tpx & 1);
-                    // positions 0..2, folded at once: p0 = m0 + (m1 + m2), sp = m1 + m2, dp = m1 - m2
-                    float p0[8], sp[8], dp[8];
+                    f32x4 rv[3][2];
+                    if (!(W4_ABL & 2)) {
+                        __syncthreads();                    // every wave is done reading the slot
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const f32x2 m0 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(0, 4 * cgx + c, xq) + xo);
-                        const f32x2 m1 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(1, 4 * cgx + c, xq) + xo);
-                        const f32x2 m2 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(2, 4 * cgx + c, xq) + xo);
+                        for (int jj = 0; jj < 3; jj++)
 #pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            sp[2 * c + k] = m1[k] + m2[k];
-                            dp[2 * c + k] = m1[k] - m2[k];
-                            p0[2 * c + k] = m0[k] + sp[2 * c + k];
-                        }
-                    }
-                    if (!(W4_ABL & 2)) __syncthreads();
-                    if (jh == 1 && !(W4_ABL & 2)) { W4_X_WRITE() }
-                    if (!(W4_ABL & 2)) __syncthreads();
-#undef W4_X_WRITE
-                    // positions 3..5, a channel (two tiles) at a time: R[b] = sum_j A^T[b][j] M[i][j], then Y[a][b] += A^T[a][i] R[b]
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const f32x2 m3 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(0, 4 * cgx + c, xq) + xo);
-                        const f32x2 m4 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(1, 4 * cgx + c, xq) + xo);
-                        const f32x2 m5 = *reinterpret_cast<const f32x2 *>(X + w4_x_index(2, 4 * cgx + c, xq) + xo);
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const int e = 2 * c + k;
-                            const float sq = m3[k] + m4[k], dq = m3[k] - m4[k];
-                            float R[4];
-                            R[0] = p0[e] + sq;
-                            R[1] = __builtin_fmaf(2.0f, dq, dp[e]);
-                            R[2] = __builtin_fmaf(4.0f, sq, sp[e]);
-                            R[3] = __builtin_fmaf(8.0f, dq, dp[e]) + m5[k];
-                            if (W4_ABL & 8) { y[0][e] += R[0] + R[1] + R[2] + R[3]; continue; }
-#pragma unroll
-                            for (int b = 0; b < 4; b++) {
-                                y[b][e] = __builtin_fmaf(c0, R[b], y[b][e]);
-                                y[4 + b][e] = __builtin_fmaf(c1, R[b], y[4 + b][e]);
-                                y[8 + b][e] = __builtin_fmaf(c2, R[b], y[8 + b][e]);
-                                y[12 + b][e] = __builtin_fmaf(c3, R[b], y[12 + b][e]);
+                            for (int h = 0; h < 2; h++) {
+                                const f32x4 v_ = {acc[jj][8 + 4 * h], acc[jj][9 + 4 * h], acc[jj][10 + 4 * h], acc[jj][11 + 4 * h]};
+                                *reinterpret_cast<f32x4 *>(xw + (2 * jj + h) * 256) = v_;
                             }
+                        __syncthreads();
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) rv[jj][h] = *reinterpret_cast<const f32x4 *>(xr + (2 * jj + h) * 256);
+                    // the pass's closing barrier, here: X is read (the next step's DMA may overwrite it) and the next step's slabs have landed; the
+                    // transform below runs into the next step's MFMAs without another meeting of the waves
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    __syncthreads();
+                    // R[b] = sum_j A^T[b][j] M[i][j] (the two kinds of wave differ in which half of the row is their own: a branch around this piece only --
+                    // around the Y update as well it costs hipcc 259 spilled registers), then Y[a][b] += A^T[a][i] R[b], two tiles at a time
+#define W4_ROW(LO_, HI_)                                                                                 \
+    _Pragma("unroll") for (int k2 = 2 * h2; k2 < 2 * h2 + 2; k2++)                                       \
+    {                                                                                                    \
+        const f32x2 m0 = LO_(0, k2), m1 = LO_(1, k2), m2 = LO_(2, k2), m3 = HI_(0, k2), m4 = HI_(1, k2), m5 = HI_(2, k2); \
+        const f32x2 sp = m1 + m2, dp = m1 - m2, p0 = m0 + sp, sq = m3 + m4, dq = m3 - m4;                \
+        R[k2][0] = p0 + sq;                                                                              \
+        R[k2][1] = w4_fma2(2.0f, dq, dp);                                                                \
+        R[k2][2] = w4_fma2(4.0f, sq, sp);                                                                \
+        R[k2][3] = w4_fma2(8.0f, dq, dp) + m5;                                                           \
+    }
+#define W4_OWN(JJ_, K2_) (f32x2{acc[JJ_][2 * (K2_)], acc[JJ_][2 * (K2_) + 1]})
+#define W4_GOT(JJ_, K2_) (f32x2{rv[JJ_][(K2_) >> 1][2 * ((K2_) & 1)], rv[JJ_][(K2_) >> 1][2 * ((K2_) & 1) + 1]})
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++) {
+                    f32x2 R[4][4];
+                    if (jh == 0) { W4_ROW(W4_OWN, W4_GOT) }
+                    else { W4_ROW(W4_GOT, W4_OWN) }
+#pragma unroll
+                    for (int k2 = 2 * h2; k2 < 2 * h2 + 2; k2++) {
+                        if (W4_ABL & 8) { y[0][k2] += R[k2][0] + R[k2][1] + R[k2][2] + R[k2][3]; continue; }
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            y[b][k2] = w4_fma2(c0, R[k2][b], y[b][k2]);
+                            y[4 + b][k2] = w4_fma2(c1, R[k2][b], y[4 + b][k2]);
+                            y[8 + b][k2] = w4_fma2(c2, R[k2][b], y[8 + b][k2]);
+                            y[12 + b][k2] = w4_fma2(c3, R[k2][b], y[12 + b][k2]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    }
+#undef W4_ROW
+#undef W4_OWN
+#undef W4_GOT
                 }
 #ifdef W4_STAMPS
                 if (kc == KC - 1) { W4_ST(2) st4[5]++; }
@@ -365,28 +376,31 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
 #endif
                 // the next step's slabs have landed (the six DMAs issued at the top of this step may still be in flight).  Step 0 of a unit
                 // waits for everything: the unit before it has just issued its output stores, and loads and stores do not retire in one order
-                if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                __syncthreads();
+                if (kc != KC - 1) {                      // (a pass's last step has met above)
+                    if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    __syncthreads();
+                }
                 W4_ST(1)
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
-        // ---- + bias, ReLU, store: a lane holds four consecutive channels of two tiles, so every store instruction writes 16 B a lane: sixteen lanes =
-        //      one pixel's 64 channels (256 B), 32 store instructions a lane and unit (one channel a lane: 128, and 8 k cycles between two units' K loops) ----
+        // ---- ReLU, store: a lane holds one channel of eight tiles, a store instruction writes 32 consecutive channels (128 B) of two pixels.  The pixel's
+        //      place in the tile is a scalar offset; a pixel outside the map turns the lane's offset out of range ----
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
         const unsigned nb4 = 4u * (unsigned)n;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int tile = 8 * wave + 2 * (lane >> 4) + t;
-            const unsigned off = tbl[tb * 128 + 2 * tile], mask = tbl[tb * 128 + 2 * tile + 1];
+        for (int k = 0; k < 8; k++) {
+            const int tile = wm * 32 + (((k >> 2) * 8 + 4 * half + (k & 3)) ^ (jh << 4));
+            const u32x2 om = *reinterpret_cast<const u32x2 *>(&tbl[tb * 128 + 2 * tile]);
+            const unsigned voff = om.x + nb4;           // an absent tile's offset (OOB) stays out of range
+            const int inv = (int)~om.y;
 #pragma unroll
             for (int p = 0; p < 16; p++) {
-                const unsigned o = ((mask >> p) & 1u) ? off + 4u * (unsigned)(((p >> 2) * W + (p & 3)) * Cout) + nb4 : OOB;
-                u32x4 v;
-#pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = __builtin_bit_cast(unsigned, wf_relu(y[p][2 * c + t] + bv[c]));
-                if (!(W4_ABL & 4) || y[p][t] == 12345.678f) __builtin_amdgcn_raw_buffer_store_b128(v, rsO, o, 0, APR_WF_STORE_AUX);
+                const unsigned o = voff | (unsigned)__builtin_amdgcn_sbfe(inv, p, 1);     // bit p of the mask clear: all ones
+                const int so = 4 * ((p >> 2) * W + (p & 3)) * Cout;
+                if (!(W4_ABL & 4) || y[p][k >> 1][k & 1] == 12345.678f)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, wf_relu(y[p][k >> 1][k & 1])), rsO, o, so, APR_WF_STORE_AUX);
             }
         }
 #ifdef W4_STAMPS
