@@ -374,11 +374,9 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                 if (kc == KC - 1) { W4_ST(2) st4[5]++; }
                 st4[4]++;
 #endif
-                // the next step's slabs have landed (the six DMAs issued at the top of this step may still be in flight).  Step 0 of a unit
-                // waits for everything: the unit before it has just issued its output stores, and loads and stores do not retire in one order
                 if (kc != KC - 1) {                      // (a pass's last step has met above)
-                    if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    // the next step's slabs have landed (this step's six may be in flight); step 1 of a unit was waited for before the last unit's stores
+                    if (s != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     __syncthreads();
                 }
                 W4_ST(1)
@@ -389,18 +387,30 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
         //      place in the tile is a scalar offset; a pixel outside the map turns the lane's offset out of range ----
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (long long)b0 * H * W * Cout), 0, 0x40000000, 0x00020000);
         const unsigned nb4 = 4u * (unsigned)n;
+        // every slab asked for so far (steps 0 and 1 of the next unit) has landed before the first store is issued: loads and stores do not retire in
+        // one order, and a count that has to cover both would make the next unit's first steps wait for the stores
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int tile = wm * 32 + (((k >> 2) * 8 + 4 * half + (k & 3)) ^ (jh << 4));
             const u32x2 om = *reinterpret_cast<const u32x2 *>(&tbl[tb * 128 + 2 * tile]);
             const unsigned voff = om.x + nb4;           // an absent tile's offset (OOB) stays out of range
             const int inv = (int)~om.y;
+            if (__builtin_amdgcn_ballot_w64(inv != 0) == 0) {          // both tiles of the instruction whole (the common case): no per-pixel work
 #pragma unroll
-            for (int p = 0; p < 16; p++) {
-                const unsigned o = voff | (unsigned)__builtin_amdgcn_sbfe(inv, p, 1);     // bit p of the mask clear: all ones
-                const int so = 4 * ((p >> 2) * W + (p & 3)) * Cout;
-                if (!(W4_ABL & 4) || y[p][k >> 1][k & 1] == 12345.678f)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, wf_relu(y[p][k >> 1][k & 1])), rsO, o, so, APR_WF_STORE_AUX);
+                for (int p = 0; p < 16; p++) {
+                    const int so = 4 * ((p >> 2) * W + (p & 3)) * Cout;
+                    if (!(W4_ABL & 4) || y[p][k >> 1][k & 1] == 12345.678f)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, wf_relu(y[p][k >> 1][k & 1])), rsO, voff, so, APR_WF_STORE_AUX);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 16; p++) {
+                    const unsigned o = voff | (unsigned)__builtin_amdgcn_sbfe(inv, p, 1);     // bit p of the mask clear: all ones
+                    const int so = 4 * ((p >> 2) * W + (p & 3)) * Cout;
+                    if (!(W4_ABL & 4) || y[p][k >> 1][k & 1] == 12345.678f)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, wf_relu(y[p][k >> 1][k & 1])), rsO, o, so, APR_WF_STORE_AUX);
+                }
             }
         }
 #ifdef W4_STAMPS
