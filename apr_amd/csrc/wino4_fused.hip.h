@@ -37,7 +37,7 @@ namespace apr {
 #endif
 
 #ifdef W4_STAMPS   // developer build (tools/w4_stamps.py): s_memtime stamps of workgroup 0, per wave: cycles in the MFMA part of the K steps [0], in their
-                   // closing wait + barrier [1], in the pass ends (exchange + transform) [2], between two units' K loops (stores, set-up) [3]; steps [4], passes [5], units [6]
+                   // closing wait + barrier [1], in the pass ends: up to the first barrier [6], exchange up to the closing barrier [7], transform [2]; between two units' K loops (stores, set-up) [3]; steps [4], passes [5]
 __device__ unsigned long long w4_stamps[8][8];
 #define W4_ST(I_) { const unsigned t_ = (unsigned)__builtin_amdgcn_s_memtime(); st4[I_] += t_ - stt; stt = t_; }
 #else
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                     f32x4 rv[3][2];
                     if (!(W4_ABL & 2)) {
                         __syncthreads();                    // every wave is done reading the slot
+                        W4_ST(6)
 #pragma unroll
                         for (int jj = 0; jj < 3; jj++)
 #pragma unroll
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
                     // transform below runs into the next step's MFMAs without another meeting of the waves
                     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     __syncthreads();
+                    W4_ST(7)
                     // R[b] = sum_j A^T[b][j] M[i][j] (the two kinds of wave differ in which half of the row is their own: a branch around this piece only --
                     // around the Y update as well it costs hipcc 259 spilled registers), then Y[a][b] += A^T[a][i] R[b], two tiles at a time
 #define W4_ROW(LO_, HI_)                                                                                 \
@@ -414,7 +416,6 @@ __global__ __launch_bounds__(512) void wino4_fused_out(const W4Args a)
             }
         }
 #ifdef W4_STAMPS
-        st4[6]++;
 #endif
         if (!more) break;
         bm = bm_n; bn = bn_n; tb ^= 1; lidl = nl;

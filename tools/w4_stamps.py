@@ -21,7 +21,7 @@ for cin in (64, 128, 256, 512):
     assert lib.apr_debug_w4_stamps(buf, 0) == 0
     eng.close()
     a = np.array(buf[:], dtype=np.float64).reshape(8, 8)
-    print(f"Cin = {cin} (layers with that input width; Cin = 512: layers 9 and 11 summed): per wave -- cycles per K step: MFMA part | closing wait + barrier || per pass: exchange + transform || per unit: between K loops | steps, passes, units")
+    print(f"Cin = {cin} (layers with that input width; Cin = 512: layers 9 and 11 summed): per wave -- cycles per K step: MFMA part | closing wait + barrier || per pass: up to the first barrier | exchange, to the closing barrier | transform || per unit: between K loops | steps, passes, units")
     for w in range(8):
-        st, ps, un = max(a[w, 4], 1), max(a[w, 5], 1), max(a[w, 6], 1)
-        print(f"  wave {w}: {a[w, 0] / st:7.0f} | {a[w, 1] / st:6.0f} || {a[w, 2] / ps:7.0f} || {a[w, 3] / un:7.0f} | {int(st)}, {int(ps)}, {int(un)}")
+        st, ps, un = max(a[w, 4], 1), max(a[w, 5], 1), max(a[w, 5], 1) / 6
+        print(f"  wave {w}: {a[w, 0] / st:7.0f} | {a[w, 1] / st:6.0f} || {a[w, 6] / ps:7.0f} | {a[w, 7] / ps:7.0f} | {a[w, 2] / ps:7.0f} || {a[w, 3] / un:7.0f} | {int(st)}, {int(ps)}, {int(un)}")
