@@ -8,17 +8,19 @@
 // and fp32 MFMA do not overlap on this chip, and F(4x4) has 4x the transform arithmetic per MFMA of F(2x2).
 // Why not 36 positions side by side: 36 x (64 tiles x 64 channels) accumulators are 2.25x the register file.  The output
 // transform is linear in the positions, so the unit is computed in SIX PASSES, one row i of the 6x6 positions each:
-// 6 position GEMMs (24 streams of 32x32 blocks over 8 waves: 48 accumulator registers a wave), then the pass's M goes through
-// LDS from the MFMA layout (wave = block x 3 positions) to the transform layout (wave = 8 tiles, lane = 4 channels x 2 tiles, all six
-// positions), where R[b] = sum_j A^T[b][j] M[i][j] and Y[a][b] += A^T[a][i] R[b] accumulate the unit's 16 outputs per
-// (tile, channel) in registers (128 a lane).  After pass 5: + bias, ReLU, 16-B stores (a lane = four channels of two tiles).
+// 6 position GEMMs (24 streams of 32x32 blocks over 8 waves: wave = block x 3 positions, 48 accumulator registers; waves w and w + 4
+// share a block and a SIMD), then the two waves of a block swap half of the pass's M through LDS (each keeps 16 tiles of its three
+// positions and gets the same 16 tiles of the other three: 24 registers a lane each way, lane-linear 16-B accesses, one round), and
+// the transform runs in the MFMA layout (lane = one channel, eight tiles): R[b] = sum_j A^T[b][j] M[i][j] and Y[a][b] += A^T[a][i] R[b]
+// accumulate the unit's 16 outputs per (tile, channel) in registers (128 a lane).  After pass 5: ReLU (Y starts from the bias) and
+// 4-byte stores, 32 consecutive channels (128 B) of two pixels an instruction.
 //
 // Work unit = 64 tiles (1024 output pixels) x 64 channels, one persistent workgroup of 8 waves per CU (wf8_grid, wf_unit order).
 // K step = 16 input channels = one slab each of V and U: [sub 2][j 6][row 64][8 floats] = 24 KiB, host- / producer-packed in
 // exactly that order with wino_fused_f2's half-swizzle, so a step's operands are two contiguous 24-KiB LDS-DMA copies
 // (every wave moves 3 KiB of each) and every ds_read_b128 feeds four MFMAs conflict-free.  Double buffered, the DMA of step
 // s+2 (which may belong to the next pass or the next unit) issued at the top of step s into the slot step s-1 read: three slots,
-// one barrier a step.  The slot a pass's last step has read is that pass's exchange buffer.
+// one barrier a step.  The slot a pass's last step has read is that pass's exchange buffer [wave 8][6][lane 64] x 16 B.
 // LDS: 3 slots x 48 KiB + two tile tables 1 KiB = 145 KiB.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -48,7 +50,7 @@ constexpr int W4_TT = 64;                        // tiles per unit
 constexpr int W4_BN = 64;                        // output channels per unit
 constexpr int W4_BK = 16;                        // input channels per K step
 constexpr int W4_SLAB = 2 * 6 * 64 * 8;          // floats of one operand slab (one pass row, one K step)
-constexpr int W4_SLOT = 2 * W4_SLAB;             // a K step's V slab + U slab = 48 KiB = the exchange buffer [3][64][64] f32
+constexpr int W4_SLOT = 2 * W4_SLAB;             // a K step's V slab + U slab = 48 KiB = the exchange buffer [8 waves][6][64 lanes] x 16 B
 constexpr int W4_LDS_BYTES = 3 * W4_SLOT * 4 + 2 * 64 * 8;
 static_assert(W4_LDS_BYTES <= 160 * 1024, "wino4_fused_out: LDS over the CU's 160 KiB");
 
@@ -139,11 +141,6 @@ struct W4Args {
     WfMagic mg;
     int n_units;
 };
-
-// exchange buffer X[3 positions][64 channels][16 quads of tiles][4]: the 16-B quad index is XOR-ed with bits of the channel (ch ^ ch >> 2), so
-// both the MFMA-side ds_write_b128 (a lane = a channel, four consecutive tile rows) and the transform-side ds_read_b64 (a lane =
-// four consecutive channels x two tiles: sixteen lanes = sixteen channel groups of one tile pair) spread the lanes of a cycle over all banks
-__device__ __forceinline__ int w4_x_index(int jj, int ch, int tile_quad) { return ((jj * 64 + ch) * 16 + (tile_quad ^ ((ch ^ (ch >> 2)) & 15))) * 4; }
 
 __device__ __forceinline__ f32x2 w4_fma2(float c, f32x2 a, f32x2 b) { return __builtin_elementwise_fma(f32x2{c, c}, a, b); }
 
