@@ -15,9 +15,11 @@ f=collections.OrderedDict()
 for r in csv.DictReader(open('gpurun_out/gn_f/p_counter_collection.csv')):
     k=(int(r['Dispatch_Id']), r['Kernel_Name'])
     f[k]=f.get(k,0.0)+float(r['Counter_Value'])
-ks=sorted(k for k in f if 'wino' in k[1])[:10]
+import re
+ks=sorted(k for k in f if 'wino' in k[1])[:15]    # the first pass: layers 3..12 in dispatch order (input transform + fused kernel on the stride-1 layers)
 d=json.loads([l for l in open('gpurun_out/gn_t.json').read().splitlines() if l.startswith('{')][-1])
-ms={l['layer']:l['ms_per_step'] for l in d['layers']}
-print('gn=$gn', round(d['ms_per_step'],1), ' '.join(f"L{l}:{f[k]*4096/1e9:.2f}GB/{ms[l]:.1f}ms" for k,l in zip(ks,range(3,13))))
+ms=[(l['layer'], l['kernel'], l['ms_per_step']) for l in d['layers'] if l['layer'] >= 3]
+short=lambda n: re.search(r'apr::([A-Za-z0-9_]+)', n).group(1)
+print('gn=$gn', round(d['ms_per_step'],1), ' '.join(f"L{l}:{short(k[1])}:{f[k]*4096/1e9:.2f}GB/{t:.1f}ms" for k,(l,kn,t) in zip(ks,ms)))
 PY
 done
