@@ -587,6 +587,34 @@ def test_full_size_sweep_properties(he_weights):
     eng.close()
 
 
+def test_pass_size_is_bit_invisible_up_to_16384_windows(he_weights):
+    # bench.py scores in passes of 16384 windows when the HBM is there (180 GB of engine memory: tile counts of 6.3 M, V tensors of 58 GB,
+    # offsets far beyond 32 bits).  The same 17 999 stream windows through engines of 4096 and of 16384 windows must give the same bits.
+    import torch
+    C, empty, trust = 4, 2, 0.5
+    free_b, _ = torch.cuda.mem_get_info(0)
+    if free_b < 200e9:
+        pytest.skip("needs 200 GB of free HBM")
+    secs, n_files = 600, 30
+    pcm = np.concatenate([model.synth_pcm(0, f, secs) for f in range(n_files)])
+    n = n_files * secs - 1
+    assert n == 17999
+    d_pcm = torch.from_numpy(pcm.view(np.uint8)).to("cuda:0")
+    outs = []
+    for mb in (4096, 16384):
+        eng = model.Engine(W.pack_blob(he_weights, C), 0, mb)
+        probs = torch.empty((n, C), dtype=torch.float64, device="cuda:0")
+        label = torch.empty(n, dtype=torch.int32, device="cuda:0")
+        match = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+        eng.score_device(d_pcm, pcm.size * 2, n, 96000, trust, empty, probs, label, match)
+        eng.sync()
+        outs.append((probs.cpu().numpy(), label.cpu().numpy(), match.cpu().numpy()))
+        eng.close()
+        del probs, label, match
+    assert np.isfinite(outs[1][0]).all() and np.abs(outs[1][0].sum(axis=1) - 1.0).max() < 1e-12
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
 def test_upsample_bit_exact_with_oracle_definition(fe):
     # 16 kHz -> 48 kHz ahead of the path (the reference leaves it to ffmpeg: src/ffmpeg/ffmpeg.go:76,113-114); no reference
     # vector exists, so the oracle here is the restatement of include/apr.h's formula -- parity with ffmpeg is NOT claimed

@@ -3,14 +3,14 @@
 into per-kernel HBM traffic per launch.
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- \
-        python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 2 --seconds 2049
+        python3 bench.py --steps 1 --warmup 0 --no-extras --no-profile --files 8 --seconds 2049
     rocprofv3 --pmc WRITE_SIZE ... -d gpurun_out/pmc_write ...
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
 
 Corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of a wide (16 B/lane) coalesced read stream, so it is doubled; WRITE_SIZE is
 taken as is (it matches the algorithmic output bytes of every kernel here exactly).  Only full
-batches are kept (the run's 1-window tail chunk is dropped).
+batches are kept (the run's short tail pass is dropped).
 """
 import collections
 import csv
@@ -34,7 +34,7 @@ def short(name):
 
 def main():
     fetch, write, out = sys.argv[1:4]
-    wpl = int(sys.argv[4]) if len(sys.argv) > 4 else 2048   # windows of the profiled pass (bench.py --max-batch)
+    wpl = int(sys.argv[4]) if len(sys.argv) > 4 else 16384   # windows of the profiled pass (bench.py --max-batch)
     f, w = load(fetch), load(write)
     per = collections.OrderedDict()
     fl = list(f.items())

@@ -3,7 +3,7 @@
 import collections, csv, json, re, shutil, subprocess, sys
 
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
-subprocess.check_call([sys.executable, "tools/pmc_traffic.py", "gpurun_out/pmc_fetch", "gpurun_out/pmc_write", f"profiles/{R}_pmc_traffic.json", "4096"])
+subprocess.check_call([sys.executable, "tools/pmc_traffic.py", "gpurun_out/pmc_fetch", "gpurun_out/pmc_write", f"profiles/{R}_pmc_traffic.json", sys.argv[2] if len(sys.argv) > 2 else "16384"])
 shutil.copy("gpurun_out/prof_round/p_kernel_stats.csv", f"profiles/{R}_bench_kernel_stats.csv")
 shutil.copy("gpurun_out/bench_prof_b.json", f"profiles/{R}_bench_under_rocprof.json")
 
@@ -40,5 +40,5 @@ for n, a in out.items():
     a["mfma_util"] = a["mfma_busy_cycles"] / a["gui_active"] / 128.0
     print(f"{n:40s} n={a['launches']:3d} clk={a['clock_GHz']:.2f} GHz  mfma util={a['mfma_util']:.3f}")
 json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (sum over SIMDs) / (GRBM_GUI_ACTIVE summed over 8 XCDs x 128 SIMDs per XCD / 8); "
-                   "clock = GRBM_GUI_ACTIVE/8/duration; bench.py --files 2 --seconds 2049 (one 4096-window pass + 1-window tail)",
+                   "clock = GRBM_GUI_ACTIVE/8/duration; bench.py --files 8 --seconds 2049 (one 16384-window pass + 7-window tail)",
            "kernels": out}, open(f"profiles/{R}_pmc_mfma_busy.json", "w"), indent=1)
