@@ -167,6 +167,32 @@ def test_librosa_flavour_restatement_properties(clips):
     assert np.abs(go[:, 2:182] - out[:, 4:184]).max() > 1e-3
 
 
+def test_librosa_flavour_against_an_independent_implementation(clips):
+    # librosa itself is absent, so this flavour stays "parity unpinned" -- but `transformers.audio_utils` (installed here, written to reproduce
+    # librosa) is a third party's restatement of the same functions: the mel basis with the reference's arguments (ai/model.py:28-34: htk=True,
+    # the default Slaney area norm, 0 .. sr/2) and the whole of audio_to_spectrogram (ai/model.py:184-204: centred zero-padded STFT with the
+    # periodic Hann window, power, mel, power_to_db(ref=max, top_db 80), clip, (x + 80) / 80).
+    A = pytest.importorskip("transformers.audio_utils")
+    mel = A.mel_filter_bank(1025, 128, 0.0, 24000.0, 48000, norm="slaney", mel_scale="htk")          # [1025][128]
+    basis = oracle.librosa_mel_basis()
+    assert np.abs(mel.T - basis).max() <= 1e-8                                                         # f32 rounding of the oracle's table
+    # the Slaney SCALE (librosa's default without htk=True) is another matrix altogether: the argument matters
+    assert np.abs(A.mel_filter_bank(1025, 128, 0.0, 24000.0, 48000, norm="slaney", mel_scale="slaney").T - basis).max() > 1e-2
+    win = A.window_function(2048, "hann", periodic=True)
+    rng = np.random.default_rng(3)
+    t = np.arange(96000) / 48000.0
+    xs = [oracle.normalize_audio(clips[k]) for k in ("test_smalldog", "test_combo")]
+    xs.append((0.1 * rng.standard_normal(96000) + 0.3 * np.sin(2 * np.pi * 440 * t) * np.exp(-3 * t)).astype(np.float32))
+    for x in xs:
+        S = A.spectrogram(x.astype(np.float64), win, 2048, 512, power=2.0, center=True, pad_mode="constant",
+                          mel_filters=mel.astype(np.float64), mel_floor=1e-10, dtype=np.float64)
+        db = A.power_to_db(S, reference=float(S.max()), min_value=1e-10, db_range=80.0)
+        want = (np.clip(db, -80.0, 0.0) + 80.0) / 80.0
+        got = oracle.prepare_librosa(x)
+        assert got.shape == want.shape == (128, 188)
+        assert np.abs(got - want).max() <= 2e-6
+
+
 @pytest.mark.parametrize("init,seed,tol", [("he", 0, 2e-4), ("torch", 1, 1e-6)])
 def test_cnn_matches_reference_noisedetector_golden(init, seed, tol):
     specs = np.load(os.path.join(GOLDEN, "cnn_input_specs.npy"))
