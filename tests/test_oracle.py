@@ -172,7 +172,15 @@ def test_librosa_flavour_against_an_independent_implementation(clips):
     # librosa) is a third party's restatement of the same functions: the mel basis with the reference's arguments (ai/model.py:28-34: htk=True,
     # the default Slaney area norm, 0 .. sr/2) and the whole of audio_to_spectrogram (ai/model.py:184-204: centred zero-padded STFT with the
     # periodic Hann window, power, mel, power_to_db(ref=max, top_db 80), clip, (x + 80) / 80).
-    A = pytest.importorskip("transformers.audio_utils")
+    import sys
+    stub = sys.modules.get("librosa")       # another test's stand-in for the absent package (no __spec__) would trip transformers' availability probe
+    if stub is not None and getattr(stub, "__spec__", None) is None:
+        del sys.modules["librosa"]
+    try:
+        A = pytest.importorskip("transformers.audio_utils")
+    finally:
+        if stub is not None:
+            sys.modules.setdefault("librosa", stub)
     mel = A.mel_filter_bank(1025, 128, 0.0, 24000.0, 48000, norm="slaney", mel_scale="htk")          # [1025][128]
     basis = oracle.librosa_mel_basis()
     assert np.abs(mel.T - basis).max() <= 1e-8                                                         # f32 rounding of the oracle's table
